@@ -1,0 +1,213 @@
+/*
+ * locus_hip.h -- C ABI of liblocus_hip.so, the MI355X (gfx950) implementation of the
+ * CAVI-sweep hot path of the `locus` R package.
+ *
+ * Conventions (same as the reference, src/locus_types.h:8-13):
+ *   - every matrix is `double`, column-major, unit inner stride, no alignment
+ *     requirement beyond 8 bytes;  A[r, c] = A[r + c * nrow];
+ *   - `shuffled_ind` holds 0-based covariate indices stored as doubles
+ *     (R/locus_core.R:88, src/coreLoop.cpp:31,38) and must be a permutation of 0..p-1;
+ *   - gam_vb, beta_vb, mat_x_m1, mu_beta_vb are updated IN PLACE
+ *     (src/coreLoop.cpp:21,26-28); everything else is read-only;
+ *   - functions return 0 on success, a negative LOCUS_HIP_E* code or a positive
+ *     hipError_t otherwise; locus_hip_last_error() gives the text (thread-local).
+ *
+ * Section 1 mirrors, one to one, the eight `.Call` routines the reference registers
+ * (src/RcppExports.cpp:191-201) with the shapes R passes implicitly made explicit
+ * (n = nrow(X), p = ncol(X), d = ncol(Y)).  Host pointers; stateless; synchronous.
+ *
+ * Section 2 is the device-resident API the drivers use (device pointers, asynchronous
+ * on the given hipStream_t, passed as void*; NULL = default stream).  It has no
+ * counterpart in the reference, which has no device; it exists so that the p x d
+ * state never crosses PCIe between CAVI iterations.
+ */
+#ifndef LOCUS_HIP_H
+#define LOCUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOCUS_HIP_EINVAL (-1)       /* bad argument (shape, null pointer, ...)   */
+#define LOCUS_HIP_EUNSUPPORTED (-2) /* shape outside what the kernels cover      */
+#define LOCUS_HIP_EPERM (-3)        /* shuffled_ind is not a permutation of 0..p-1 */
+
+const char* locus_hip_last_error(void);
+int locus_hip_version(void);      /* 100 * major + minor */
+int locus_hip_device_count(void); /* visible HIP devices, 0 if none / no driver */
+
+/* ------------------------------------------------------------------------- */
+/* 1. Stateless mirrors of the reference's .Call routines (host pointers)    */
+/* ------------------------------------------------------------------------- */
+
+/* replaces coreLoop, src/coreLoop.cpp:19-54 (R wrapper R/RcppExports.R:16-18) */
+int locus_hip_core_loop(const double* X, const double* Y, double* gam_vb,
+                        const double* log_om_vb, const double* log_1_min_om_vb,
+                        double log_sig2_inv_vb, const double* log_tau_vb, double* beta_vb,
+                        double* mat_x_m1, double* mu_beta_vb, const double* sig2_beta_vb,
+                        const double* tau_vb, const double* shuffled_ind, double c,
+                        int64_t n, int64_t p, int64_t d);
+
+/* replaces coreZLoop, src/coreLoop.cpp:60-96 (R/RcppExports.R:20-22) */
+int locus_hip_core_z_loop(const double* X, const double* Y, double* gam_vb,
+                          const double* log_om_vb, const double* log_1_min_om_vb,
+                          double log_sig2_inv_vb, const double* log_tau_vb, double* beta_vb,
+                          double* mat_x_m1, const double* mat_z_mu, double* mu_beta_vb,
+                          const double* sig2_beta_vb, const double* tau_vb,
+                          const double* shuffled_ind, double c,
+                          int64_t n, int64_t p, int64_t d);
+
+/* replaces coreLogitLoop, src/coreLoop.cpp:101-133 (R/RcppExports.R:24-26);
+ * sig2_beta_vb is p x d, Y already has 1/2 subtracted */
+int locus_hip_core_logit_loop(const double* X, const double* Y, double* gam_vb,
+                              const double* log_om_vb, const double* log_1_min_om_vb,
+                              double log_sig2_inv_vb, double* beta_vb, double* mat_x_m1,
+                              const double* mat_z_mu, double* mu_beta_vb, const double* psi_vb,
+                              const double* sig2_beta_vb, const double* shuffled_ind,
+                              int64_t n, int64_t p, int64_t d);
+
+/* replaces coreProbitLoop, src/coreLoop.cpp:139-171 (R/RcppExports.R:28-30);
+ * scalar sig2_beta_vb */
+int locus_hip_core_probit_loop(const double* X, const double* W, double* gam_vb,
+                               const double* log_om_vb, const double* log_1_min_om_vb,
+                               double log_sig2_inv_vb, double* beta_vb, double* mat_x_m1,
+                               const double* mat_z_mu, double* mu_beta_vb, double sig2_beta_vb,
+                               const double* shuffled_ind, int64_t n, int64_t p, int64_t d);
+
+/* replaces coreStructLoop, src/coreStructLoop.cpp:18-52 (R/RcppExports.R:32-34) */
+int locus_hip_core_struct_loop(const double* X, const double* Y, double* gam_vb,
+                               const double* log_Phi_mu_theta_vb,
+                               const double* log_1_min_Phi_mu_theta_vb, double log_sig2_inv_vb,
+                               const double* log_tau_vb, double* beta_vb, double* mat_x_m1,
+                               double* mu_beta_vb, const double* sig2_beta_vb,
+                               const double* tau_vb, const double* shuffled_ind,
+                               int64_t n, int64_t p, int64_t d);
+
+/* replaces coreBatch, src/coreBatch.cpp:19-42 (R/RcppExports.R:4-6) */
+int locus_hip_core_batch(const double* X, const double* Y, double* gam_vb,
+                         const double* log_om_vb, const double* log_1_min_om_vb,
+                         double log_sig2_inv_vb, const double* log_tau_vb, double* beta_vb,
+                         double* mat_x_m1, double* mu_beta_vb, const double* sig2_beta_vb,
+                         const double* tau_vb, int64_t n, int64_t p, int64_t d);
+
+/* replaces coreZBatch, src/coreBatch.cpp:48-73 (R/RcppExports.R:8-10) */
+int locus_hip_core_z_batch(const double* X, const double* Y, double* gam_vb,
+                           const double* log_om_vb, const double* log_1_min_om_vb,
+                           double log_sig2_inv_vb, const double* log_tau_vb, double* beta_vb,
+                           double* mat_x_m1, const double* mat_z_mu, double* mu_beta_vb,
+                           const double* sig2_beta_vb, const double* tau_vb,
+                           int64_t n, int64_t p, int64_t d);
+
+/* replaces coreProbitBatch, src/coreBatch.cpp:78-100 (R/RcppExports.R:12-14) */
+int locus_hip_core_probit_batch(const double* X, const double* W, double* gam_vb,
+                                const double* log_om_vb, const double* log_1_min_om_vb,
+                                double log_sig2_inv_vb, double* beta_vb, double* mat_x_m1,
+                                const double* mat_z_mu, double* mu_beta_vb, double sig2_beta_vb,
+                                int64_t n, int64_t p, int64_t d);
+
+/* ------------------------------------------------------------------------- */
+/* 2. Device-resident API (device pointers, async on `stream`)                */
+/* ------------------------------------------------------------------------- */
+
+/* Leading dimension (doubles) of the packed X for n rows: n rounded up to 128. */
+int64_t locus_hip_packed_ld(int64_t n);
+
+/* X (n x p column-major) -> Xp [p][ld] zero-padded columns and xtx[j] = X[,j]'X[,j].
+ * Done once per data set (the reference reads X in place, src/coreLoop.cpp:40). */
+int locus_hip_pack_x_dev(const double* X, int64_t n, int64_t p, double* Xp, double* xtx,
+                         void* stream);
+
+/* Bytes of scratch a sweep over p covariates needs (step records, permutation check). */
+int64_t locus_hip_sweep_workspace_bytes(int64_t p);
+
+typedef struct locus_hip_sweep_args {
+    int64_t n, p, d;            /* d = responses resident on this device            */
+    const double* Xp;           /* [p][ld] from locus_hip_pack_x_dev                 */
+    const double* xtx;          /* [p]                                              */
+    const double* shuffled_ind; /* [p]  0-based indices as doubles                   */
+    const double* lo;           /* [p]  log_om_vb        | log_Phi_mu_theta_vb       */
+    const double* l1;           /* [p]  log_1_min_om_vb  | log_1_min_Phi_mu_theta_vb */
+    /* identity family (coreLoop / coreZLoop / coreStructLoop / coreProbitLoop):      */
+    const double* scale;        /* [d]  (c * sig2_beta_k) * tau_k   (probit: sig2_beta) */
+    const double* hinv;         /* [d]  1 / (2 sig2_beta_k)                          */
+    const double* cst;          /* [d]  -(log_tau_k + log_sig2_inv + log sig2_beta_k)/2 */
+    const double* s2k;          /* [d]  sig2_beta_k                                  */
+    double cfac;                /* annealing factor c (1 if none)                    */
+    /* logit (coreLogitLoop):                                                         */
+    const double* s2;           /* [p][d] sig2_beta_vb, response-contiguous          */
+    const double* xwx;          /* [p][d] sum_i X_ij^2 * 2 psi_ik                    */
+    const double* W2;           /* n x d column-major, 2 * psi_vb                    */
+    double half_lsi;            /* log_sig2_inv_vb / 2                               */
+    /* in / out                                                                       */
+    double* R;                  /* n x d column-major residual                       */
+    double* state;              /* [3][p][d]: gam_vb, mu_beta_vb, beta_vb planes     */
+    double* stats;              /* [4][d] or NULL: sum_j gam, sum_j m2_beta, sum_j beta^2,
+                                   sum_i R^2 after the sweep                         */
+    void* workspace;            /* >= locus_hip_sweep_workspace_bytes(p)             */
+    int64_t workspace_bytes;
+    int64_t nsteps;             /* covariates to visit (0 or p = full sweep)          */
+    int32_t cfg[4];             /* NPL, C, S, G kernel geometry; all 0 = automatic    */
+} locus_hip_sweep_args;
+
+/* One CAVI sweep over the covariates in `shuffled_ind` order; logit = 0 runs the
+ * identity-family update, logit = 1 the coreLogitLoop update.  A non-permutation
+ * makes the sweep a no-op and is reported by locus_hip_sweep_status_dev(). */
+int locus_hip_sweep_dev(const locus_hip_sweep_args* args, int logit, void* stream);
+
+/* Synchronises `stream` and returns 0, or LOCUS_HIP_EPERM if the last sweep that used
+ * `workspace` (sized for p covariates) was given an invalid shuffled_ind. */
+int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream);
+
+/* Geometry the library would pick for (n, d): fills cfg[4] = NPL, C, S, G. */
+int locus_hip_sweep_config(int64_t n, int64_t d, int logit, int32_t* cfg);
+
+/* out = Y - A - Zmu                       (W2 == NULL; same formula both directions)
+ * out = Y - W2 * (A + Zmu)                (W2 != NULL, to_residual = 1)
+ * out = (Y - A) / W2 - Zmu                (W2 != NULL, to_residual = 0)
+ * all n x d column-major; Zmu may be NULL. */
+int locus_hip_residual_dev(const double* Y, const double* A, const double* Zmu,
+                           const double* W2, double* out, int64_t n, int64_t d,
+                           int to_residual, void* stream);
+
+/* out[cols][rows] = transpose(in[rows][cols]) (row-major).  An R p x d matrix is a
+ * row-major [d][p]; transpose(rows = d, cols = p) gives the [p][d] state plane. */
+int locus_hip_transpose_dev(const double* in, double* out, int64_t rows, int64_t cols,
+                            void* stream);
+
+/* rs_gam[j] = sum_k gam[j][k]  (rowSums(gam_vb), R/locus_core.R:95) and, if ent != NULL,
+ * ent[j] = sum_k gam log(gam + eps) + (1 - gam) log(1 - gam + eps)  (R/elbo.R:52). */
+int locus_hip_gamma_rows_dev(const double* gam, double* rs_gam, double* ent, int64_t p,
+                             int64_t d, double eps, void* stream);
+
+/* Column sums over covariates of the state without a sweep (initialisation,
+ * R/locus_core.R:36-42): writes beta = gam * mu into plane 2 and
+ * st_partial[chunk][3][d] = partial sums of gam, gam (mu^2 + s2), beta^2.
+ * s2 comes from s2k[d] (identity family) or s2jk[p][d] (logit); one may be NULL. */
+int locus_hip_state_cols_dev(double* state, const double* s2k, const double* s2jk,
+                             double* st_partial, int64_t p, int64_t d, int64_t nchunks,
+                             void* stream);
+
+/* C[m x n] = alpha * op(A) op(B) + beta * C on the fp64 matrix cores; element (i, k) of
+ * op(A) is A[i * sa_m + k * sa_k] (squared first if sqA), likewise B and C. */
+int locus_hip_gemm_dev(int64_t m, int64_t n, int64_t k, double alpha, const double* A,
+                       int64_t sa_m, int64_t sa_k, int sqA, const double* B, int64_t sb_k,
+                       int64_t sb_n, int sqB, double beta, double* C, int64_t sc_m,
+                       int64_t sc_n, void* stream);
+
+/* Element-wise part of coreBatch / coreZBatch / coreProbitBatch on [p][d] planes
+ * (src/coreBatch.cpp:32-39):  T = X'(Y - M [- Zmu]) on entry in `mu` plane;
+ *   mu = (T + (n-1) beta) * fac_k ; gam = exp(-log1pexp(...)) ; beta = mu * gam.
+ * fac, hinv, cstk are [d]: fac = sig2_beta_k tau_k (probit: sig2_beta),
+ * hinv = 1/(2 sig2_beta_k), cstk = log_tau_k/2 + log(sig2_beta_k)/2 (probit: log(sig2_beta)/2
+ * with probit = 1, which also changes the order of the additions, :94-95). */
+int locus_hip_batch_update_dev(double* state, const double* lo, const double* l1,
+                               const double* fac, const double* hinv, const double* cstk,
+                               double log_sig2_inv, double nm1, int probit, int64_t p,
+                               int64_t d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCUS_HIP_H */

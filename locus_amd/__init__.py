@@ -1,0 +1,15 @@
+"""locus_amd -- MI355X-native implementation of the CAVI-sweep hot path of `locus`.
+
+Layout:
+  csrc/            HIP kernels + the C ABI (include/locus_hip.h) -> liblocus_hip.so
+  _lib.py          ctypes bindings of the C ABI (no fallback: fails without the .so / GPU)
+  core.py          coreLoop, coreBatch, ... : the reference's eight native routines
+  device.py        device-resident state and kernels for the drivers
+  update_vb.py, elbo.py, locus_core.py, ...   host side of the drivers (mirrors R/)
+"""
+from . import _lib  # noqa: F401
+from .core import (coreBatch, coreLogitLoop, coreLoop, coreProbitBatch,  # noqa: F401
+                   coreProbitLoop, coreStructLoop, coreZBatch, coreZLoop)
+
+__all__ = ["coreLoop", "coreZLoop", "coreLogitLoop", "coreProbitLoop", "coreStructLoop",
+           "coreBatch", "coreZBatch", "coreProbitBatch"]

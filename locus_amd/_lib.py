@@ -1,0 +1,107 @@
+"""ctypes loader of liblocus_hip.so (the C ABI declared in include/locus_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or no GPU is
+visible, every compute entry point raises.  (The CPU oracle under oracle/ is test
+infrastructure and is never imported from this package.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblocus_hip.so")
+
+c_double_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_dbl = ctypes.c_double
+_ptr = ctypes.c_void_p
+_int = ctypes.c_int
+
+
+class LocusHipError(RuntimeError):
+    """Non-zero status from liblocus_hip; `.code` holds it."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"liblocus_hip error {code}: {msg}")
+        self.code = code
+
+
+class SweepArgs(ctypes.Structure):
+    """struct locus_hip_sweep_args (include/locus_hip.h)."""
+    _fields_ = [
+        ("n", _i64), ("p", _i64), ("d", _i64),
+        ("Xp", _ptr), ("xtx", _ptr), ("shuffled_ind", _ptr), ("lo", _ptr), ("l1", _ptr),
+        ("scale", _ptr), ("hinv", _ptr), ("cst", _ptr), ("s2k", _ptr), ("cfac", _dbl),
+        ("s2", _ptr), ("xwx", _ptr), ("W2", _ptr), ("half_lsi", _dbl),
+        ("R", _ptr), ("state", _ptr), ("stats", _ptr),
+        ("workspace", _ptr), ("workspace_bytes", _i64), ("nsteps", _i64),
+        ("cfg", ctypes.c_int32 * 4),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/locus_hip.h declares
+_LOOP_COMMON = [_ptr] * 5 + [_dbl]
+SIGNATURES = {
+    "locus_hip_last_error": (ctypes.c_char_p, []),
+    "locus_hip_version": (_int, []),
+    "locus_hip_device_count": (_int, []),
+    "locus_hip_core_loop": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                   _ptr, _ptr, _dbl, _i64, _i64, _i64]),
+    "locus_hip_core_z_loop": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr,
+                                     _ptr, _ptr, _ptr, _ptr, _dbl, _i64, _i64, _i64]),
+    "locus_hip_core_logit_loop": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr,
+                                         _ptr, _ptr, _ptr, _i64, _i64, _i64]),
+    "locus_hip_core_probit_loop": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr,
+                                          _ptr, _dbl, _ptr, _i64, _i64, _i64]),
+    "locus_hip_core_struct_loop": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr,
+                                          _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64]),
+    "locus_hip_core_batch": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr,
+                                    _ptr, _ptr, _i64, _i64, _i64]),
+    "locus_hip_core_z_batch": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr,
+                                      _ptr, _ptr, _ptr, _i64, _i64, _i64]),
+    "locus_hip_core_probit_batch": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr,
+                                           _ptr, _dbl, _i64, _i64, _i64]),
+    "locus_hip_packed_ld": (_i64, [_i64]),
+    "locus_hip_pack_x_dev": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr]),
+    "locus_hip_sweep_workspace_bytes": (_i64, [_i64]),
+    "locus_hip_sweep_dev": (_int, [ctypes.POINTER(SweepArgs), _int, _ptr]),
+    "locus_hip_sweep_status_dev": (_int, [_ptr, _i64, _ptr]),
+    "locus_hip_sweep_config": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int32)]),
+    "locus_hip_residual_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _ptr]),
+    "locus_hip_transpose_dev": (_int, [_ptr, _ptr, _i64, _i64, _ptr]),
+    "locus_hip_gamma_rows_dev": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _dbl, _ptr]),
+    "locus_hip_state_cols_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr]),
+    "locus_hip_gemm_dev": (_int, [_i64, _i64, _i64, _dbl, _ptr, _i64, _i64, _int, _ptr, _i64, _i64,
+                                  _int, _dbl, _ptr, _i64, _i64, _ptr]),
+    "locus_hip_batch_update_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _dbl, _int,
+                                          _i64, _i64, _ptr]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if liblocus_hip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C locus_amd/csrc` (there is no CPU fallback)")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(code):
+    """Raise LocusHipError for a non-zero status."""
+    if code != 0:
+        msg = lib().locus_hip_last_error()
+        raise LocusHipError(code, msg.decode() if msg else "")
+
+
+def device_count():
+    return lib().locus_hip_device_count()

@@ -1,0 +1,80 @@
+"""GPU parity of the five sweep routines (coreLoop, coreZLoop, coreStructLoop,
+coreProbitLoop, coreLogitLoop) against the CPU oracle, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_parity, call_variant, inputs_for
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = ["identity", "z", "struct", "probit", "logit"]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("shape", [(200, 500, 20), (100, 75, 20), (64, 33, 1), (257, 40, 7),
+                                   (1000, 64, 41)])
+def test_sweep_matches_oracle(oracle, hip, variant, shape):
+    n, p, d = shape
+    inp = inputs_for(variant, n, p, d, seed=n + p + d)
+    ref = call_variant(oracle, variant, inp)
+    got = call_variant(hip, variant, inp)
+    assert_parity(got, ref, what=f"{variant} {shape}")
+
+
+# explicit kernel geometries NPL,C,S,G : every reduction / staging path
+GEOMS = ["4,1,1,1", "4,2,1,1", "4,4,1,2", "4,5,1,1", "4,8,1,1", "4,10,1,2", "4,16,1,1",
+         "2,4,2,1", "2,5,2,2", "2,16,2,1", "8,5,1,2", "8,10,1,2", "16,5,1,4", "16,4,1,4",
+         "2,2,4,1", "2,10,4,1", "4,4,4,1", "8,2,2,2"]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
+    npl, c, s, g = map(int, geom.split(","))
+    n = min(64 * npl * s, 64 * npl * s - 7)  # ragged rows inside the padded column
+    p, d = 37, 2 * c * g + 3                  # ragged responses: partial last workgroup
+    inp = inputs_for("identity", n, p, d, seed=11)
+    ref = call_variant(oracle, "identity", inp)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", geom)
+    got = call_variant(hip, "identity", inp)
+    assert_parity(got, ref, what=f"identity geom {geom}")
+
+
+@pytest.mark.parametrize("geom", ["4,1,1,1", "4,4,1,1", "4,5,1,2", "2,8,2,1", "8,4,1,2", "8,5,1,2",
+                                  "16,2,1,4", "2,2,4,1"])
+def test_sweep_geometries_logit(oracle, hip, geom, monkeypatch):
+    npl, c, s, g = map(int, geom.split(","))
+    n = 64 * npl * s - 5
+    p, d = 29, 2 * c * g + 1
+    inp = inputs_for("logit", n, p, d, seed=5)
+    ref = call_variant(oracle, "logit", inp)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", geom)
+    got = call_variant(hip, "logit", inp)
+    assert_parity(got, ref, what=f"logit geom {geom}")
+
+
+def test_annealing_factor(oracle, hip):
+    inp = inputs_for("identity", 200, 60, 9, seed=3, c=0.37)
+    ref = call_variant(oracle, "identity", inp)
+    got = call_variant(hip, "identity", inp)
+    assert_parity(got, ref, what="identity c=0.37")
+
+
+def test_bad_permutation_rejected(hip):
+    from locus_amd._lib import LocusHipError
+    inp = inputs_for("identity", 100, 10, 3, seed=1)
+    inp["shuffled_ind"] = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 8], dtype=np.float64)
+    before = inp["gam_vb"].copy()
+    with pytest.raises(LocusHipError) as ei:
+        call_variant(hip, "identity", inp)
+    assert ei.value.code == -3
+    assert np.array_equal(before, inp["gam_vb"])
+
+
+def test_two_sweeps_in_a_row_deterministic(hip):
+    inp = inputs_for("identity", 200, 120, 20, seed=8)
+    a = call_variant(hip, "identity", inp)
+    b = call_variant(hip, "identity", inp)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"{k} differs run to run"
