@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""bench.py -- beta updates/s of the CAVI iteration on MI355X (BASELINE.json metric).
+
+Workload (default, N = 1): BASELINE config C3, identity link, n = 1000, p = 50 000,
+d = 10 000, fp64, synthetic data of the reference's simulation shape
+(R/locus.R:152-187), default hyper-parameters / initial values
+(R/set_hyper_init.R:321-419, 750-874).  It fits one GPU (X 0.4 GB, state 12 GB).
+
+A "step" is ONE full CAVI iteration of locus_core_ (R/locus_core.R:49-211): hyper-parameter
+updates, the coreLoop sweep over all p covariates in a fresh random order, rowSums /
+entropy reductions, the packed all-reduce and the ELBO.  value = p * d / step time.
+With --gpus N the d responses are sharded over N ranks (X replicated, one RCCL
+all-reduce of p + 2 doubles per step): total work is fixed => "scaling": "strong".
+
+The JSON line also carries
+  roofline     : the sweep kernel against the HBM roofline with the ALGORITHMIC bytes of
+                 SURVEY.md §8(d) (16 n + 8 n / d_loc + 32 per update).  The residual lives
+                 in VGPRs for the whole sweep, so the fraction exceeds 1 -- the binding
+                 roofline is fp64 FMA, reported as roofline_fp64 (4 n + 60 flop / update,
+                 78.6 TFLOP/s peak).  `traffic` is the PMC-measured HBM bytes per launch
+                 from profiles/ (null if no profile of this shape is committed).
+  cpu_baseline : the C oracle (literal restatement of src/coreLoop.cpp, gcc -O2, 1 thread)
+                 timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1000)
+    ap.add_argument("--p", type=int, default=50000)
+    ap.add_argument("--d", type=int, default=10000)
+    ap.add_argument("--p0", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-covariates", type=int, default=0,
+                    help="covariates of the CPU sample (0 = sized for ~15 s)")
+    return ap.parse_args()
+
+
+def make_data(n, p, d, p0, k_lo, k_hi, seed=123):
+    """X (n x p, standardised) and this rank's slice of the centred Y, per SURVEY §8(d)."""
+    rng = np.random.default_rng(seed)
+    X = rng.binomial(2, 0.25, size=(p, n)).astype(np.float32)  # [p][n]: column j contiguous
+    sd = X.std(axis=1, ddof=1)
+    for j in np.nonzero(sd == 0)[0]:
+        X[j, rng.integers(n)] += 1.0
+    X = X.astype(np.float64)
+    X -= X.mean(axis=1, keepdims=True)
+    X /= X.std(axis=1, ddof=1, keepdims=True)
+    d0 = int(0.8 * d)
+    ind_p0 = np.sort(rng.choice(p, size=p0, replace=False))
+    ind_d0 = np.sort(rng.choice(d, size=d0, replace=False))
+    beta = np.where(rng.random((p0, d0)) < 0.2, rng.normal(size=(p0, d0)), 0.0)
+    Y = rng.normal(scale=0.5, size=(n, d))
+    Y[:, ind_d0] += X[ind_p0].T @ beta
+    Y -= Y.mean(axis=0)
+    var = Y.var(axis=0, ddof=1)
+    return X, np.ascontiguousarray(Y[:, k_lo:k_hi].T), float(np.median(var))
+
+
+def cpu_baseline(n, d, ncov, seed=7):
+    """Oracle coreLoop (oracle/locus_oracle.c) on `ncov` covariates x all d responses."""
+    from oracle import c_oracle
+    c_oracle.build()
+    from locus_amd.simulate import sweep_inputs
+    if ncov <= 0:
+        # ~6 n d flop and ~5 passes over n x d doubles per covariate; aim at ~15 s
+        probe = sweep_inputs(n, 4, d, seed=seed)
+        t0 = time.perf_counter()
+        _run_oracle(c_oracle, probe)
+        per = (time.perf_counter() - t0) / 4
+        ncov = int(max(4, min(4096, 15.0 / max(per, 1e-6))))
+    inp = sweep_inputs(n, ncov, d, seed=seed)
+    t0 = time.perf_counter()
+    _run_oracle(c_oracle, inp)
+    dt = time.perf_counter() - t0
+    return dict(value=ncov * d / dt, unit="beta updates/s", cores=1, kind="port",
+                sample=f"oracle coreLoop (gcc -O2, 1 thread) on {ncov} covariates x all {d} "
+                       f"responses, n={n} ({dt:.1f} s; cost per covariate does not depend on p); "
+                       f"host has {os.cpu_count()} logical CPUs")
+
+
+def _run_oracle(c_oracle, a):
+    c_oracle.coreLoop(a["X"], a["Y"], a["gam_vb"], a["log_om_vb"], a["log_1_min_om_vb"],
+                      a["log_sig2_inv_vb"], a["log_tau_vb"], a["beta_vb"], a["mat_x_m1"],
+                      a["mu_beta_vb"], a["sig2_beta_vb"], a["tau_vb"], a["shuffled_ind"], 1.0)
+
+
+def committed_traffic(n, p, d_loc):
+    """HBM bytes per sweep launch measured with rocprofv3 --pmc (profiles/traffic_*.json)."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.startswith("traffic_") and f.endswith(".json"):
+                try:
+                    for rec in json.load(open(os.path.join(pdir, f))):
+                        if (rec["n"], rec["p"], rec["d_loc"]) == (n, p, d_loc):
+                            best = rec["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
+    return best
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from locus_amd import device as dv
+    from locus_amd.comm import Comm, DistComm
+    from locus_amd.locus_core import IdentityEngine, IdentityHost
+    dv.require_gpu()
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        comm = DistComm()
+    else:
+        comm = Comm()
+
+    n, p, d, p0 = args.n, args.p, args.d, args.p0
+    k_lo, k_hi = comm.shard(d)
+    d_loc = k_hi - k_lo
+
+    # ---- synthetic inputs (same on every rank; Y sliced) -----------------------------
+    Xpn, Yt, med_var = make_data(n, p, d, p0, k_lo, k_hi)
+    X_dev = torch.from_numpy(Xpn).to(device).t()          # n x p, column-major storage
+    px = dv.PackedX(X_dev)
+    del X_dev, Xpn
+    Y_dev = torch.from_numpy(Yt).to(device).t()           # n x d_loc, column-major storage
+    del Yt
+    # default hyper-parameters / initial values (R/set_hyper_init.R:328-363, 765-804)
+    b = d * (p - p0) / p0
+    hyper = dict(a=np.ones(p), b=np.full(p, b), eta=np.full(d_loc, 1.0 / med_var),
+                 kappa=np.ones(d_loc), nu=1.0)
+    hyper["lambda"] = 1e-2
+    tau0 = np.full(d_loc, 1.0 / med_var)
+    rng = np.random.default_rng(123 + 7919 * rank)
+    sig2_beta0 = 1.0 / rng.gamma(2.0, 1e-2 * tau0)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(123 + rank)
+    state = torch.empty((3, p, d_loc), dtype=torch.float64, device=device)
+    state[0].uniform_(0, 1, generator=gen)                # gam ~ Beta(1, b) by inversion
+    state[0] = -torch.expm1(torch.log1p(-state[0]) / b)
+    state[1].normal_(0, 1, generator=gen)                 # mu ~ N(0, 1)
+    host = IdentityHost(n, p, d, hyper, tau0, sig2_beta0, comm)
+    eng = IdentityEngine(px, Y_dev, state, host, device)
+    eng.initialise()
+
+    perm_rng = np.random.default_rng(1)                   # same stream on every rank
+    ev = []
+
+    def step():
+        ind = perm_rng.permutation(p).astype(np.float64)
+        return eng.iterate(ind, 1.0, with_elbo=True)
+
+    # kernel timing: HIP events around the sweep launch, on the stream it is launched on
+    orig_identity = eng.sweeper.identity
+
+    def timed_identity(*a, **k):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_identity(*a, **k)
+        e1.record()
+        ev.append((e0, e1))
+    eng.sweeper.identity = timed_identity
+
+    lbs = []
+    for _ in range(args.warmup):
+        lbs.append(step())
+    comm.barrier()
+    torch.cuda.synchronize()
+    ev.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lbs.append(step())
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        import torch.distributed as dist
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev])) if ev else float("nan")
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = p * d / (dt / args.steps)
+        upd_launch = p * d_loc
+        bytes_per_update = 16.0 * n + 8.0 * n / d_loc + 32.0
+        flops_per_update = 4.0 * n + 60.0
+        ach_gbs = upd_launch * bytes_per_update / (kern_ms * 1e-3) / 1e9
+        ach_tf = upd_launch * flops_per_update / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "beta updates/sec (p*d per CAVI sweep)", "value": value,
+            "unit": "beta updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C3 identity-link CAVI iteration n={n} p={p} d={d} p0_av={p0}"
+                                   f" (d sharded over {world} GPU(s), X replicated)",
+                       "n": n, "p": p, "d": d, "d_per_gpu": d_loc,
+                       "parallelism": f"d-shard x{world}", "elbo_last": lbs[-1],
+                       "elbo_monotone": bool(np.all(np.diff(lbs) > -1.49e-8))},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS,
+                         "traffic": committed_traffic(n, p, d_loc),
+                         "kernel": "sweep_kernel (coreLoop)", "kernel_ms": kern_ms,
+                         "bytes_per_update": bytes_per_update, "updates_per_launch": upd_launch,
+                         "note": "algorithmic bytes of SURVEY §8(d); residual is register-"
+                                 "resident so frac > 1 is expected, see roofline_fp64"},
+            "roofline_fp64": {"bound": "fp64-fma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
+                              "flops_per_update": flops_per_update},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_covariates)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

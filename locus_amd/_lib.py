@@ -87,6 +87,10 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C locus_amd/csrc` (there is no CPU fallback)")
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as the
+        # system one).  It must be the copy the process loads first, otherwise torch sees no
+        # GPU and device pointers would cross two runtimes: import torch before the dlopen.
+        import torch  # noqa: F401
         h = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the symbol is missing

@@ -1,0 +1,158 @@
+"""Device-resident side of the drivers: torch tensors own the HBM, liblocus_hip does the
+work (section 2 of include/locus_hip.h).  torch is used for allocation, streams and
+torch.distributed only.
+
+Layouts:
+  Xp     [p][ld]      packed, zero padded columns of X (replicated on every GPU)
+  R      n x d_loc    column-major residual  Y - mat_x_m1 (- mat_z_mu)   | logit: Y - 2 psi (M + Zmu)
+  state  [3][p][d_loc] planes gam_vb, mu_beta_vb, beta_vb, response-contiguous
+  stats  [4][d_loc]   per-response sums produced by the sweep epilogue
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F64 = torch.float64
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available() or _lib.device_count() < 1:
+        raise RuntimeError("locus_amd needs a HIP device (no CPU fallback)")
+
+
+def colmajor(t):
+    """n x d tensor whose storage is column-major (R layout): a transposed view of [d][n]."""
+    return t.t().contiguous().t()
+
+
+def to_device_colmajor(a, device):
+    """numpy (any order) -> device tensor with column-major storage, shape kept."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    t = torch.from_numpy(np.ascontiguousarray(a.T)).to(device)  # [d][n] row-major
+    return t.t()  # n x d view, column-major storage
+
+
+def is_colmajor(t):
+    return t.dim() == 2 and t.stride(0) == 1 and t.stride(1) == t.shape[0]
+
+
+class PackedX:
+    """X packed once per data set: Xp [p][ld] and xtx[j] = X[,j]'X[,j]."""
+
+    def __init__(self, X_dev):
+        assert is_colmajor(X_dev) and X_dev.dtype == F64
+        self.n, self.p = X_dev.shape
+        self.ld = int(_lib.lib().locus_hip_packed_ld(self.n))
+        self.Xp = torch.empty((self.p, self.ld), dtype=F64, device=X_dev.device)
+        self.xtx = torch.empty((self.p,), dtype=F64, device=X_dev.device)
+        _lib.check(_lib.lib().locus_hip_pack_x_dev(_p(X_dev), self.n, self.p, _p(self.Xp),
+                                                   _p(self.xtx), _stream()))
+
+
+class Sweeper:
+    """Runs CAVI sweeps on device-resident state (wraps locus_hip_sweep_dev)."""
+
+    def __init__(self, px, d, device, cfg=None):
+        self.px = px
+        self.n, self.p, self.d = px.n, px.p, int(d)
+        nbytes = int(_lib.lib().locus_hip_sweep_workspace_bytes(self.p))
+        self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.cfg = cfg
+        self._keep = None
+
+    def _args(self, shuffled_ind, lo, l1, R, state, stats, nsteps=0):
+        a = _lib.SweepArgs()
+        a.n, a.p, a.d = self.n, self.p, self.d
+        a.Xp, a.xtx = self.px.Xp.data_ptr(), self.px.xtx.data_ptr()
+        a.shuffled_ind, a.lo, a.l1 = shuffled_ind.data_ptr(), lo.data_ptr(), l1.data_ptr()
+        a.R, a.state = R.data_ptr(), state.data_ptr()
+        a.stats = stats.data_ptr() if stats is not None else None
+        a.workspace, a.workspace_bytes = self.workspace.data_ptr(), self.workspace.numel()
+        a.nsteps = nsteps
+        if self.cfg is not None:
+            for i in range(4):
+                a.cfg[i] = int(self.cfg[i])
+        return a
+
+    def identity(self, shuffled_ind, lo, l1, scale, hinv, cst, s2k, cfac, R, state, stats=None,
+                 nsteps=0):
+        """coreLoop / coreZLoop / coreStructLoop / coreProbitLoop on the resident residual."""
+        a = self._args(shuffled_ind, lo, l1, R, state, stats, nsteps)
+        a.scale, a.hinv, a.cst, a.s2k = (scale.data_ptr(), hinv.data_ptr(), cst.data_ptr(),
+                                         s2k.data_ptr())
+        a.cfac = float(cfac)
+        self._keep = (shuffled_ind, lo, l1, scale, hinv, cst, s2k)
+        _lib.check(_lib.lib().locus_hip_sweep_dev(ctypes.byref(a), 0, _stream()))
+
+    def logit(self, shuffled_ind, lo, l1, s2, xwx, W2, half_lsi, R, state, stats=None, nsteps=0):
+        """coreLogitLoop on the resident psi-weighted residual."""
+        a = self._args(shuffled_ind, lo, l1, R, state, stats, nsteps)
+        a.s2, a.xwx, a.W2 = s2.data_ptr(), xwx.data_ptr(), W2.data_ptr()
+        a.half_lsi = float(half_lsi)
+        self._keep = (shuffled_ind, lo, l1, s2, xwx, W2)
+        _lib.check(_lib.lib().locus_hip_sweep_dev(ctypes.byref(a), 1, _stream()))
+
+    def status(self):
+        """Synchronise and raise if the last sweep saw an invalid shuffled_ind."""
+        _lib.check(_lib.lib().locus_hip_sweep_status_dev(_p(self.workspace), self.p, _stream()))
+
+
+def residual(Y, A, Zmu=None, W2=None, out=None, to_residual=True):
+    n, d = Y.shape
+    if out is None:
+        out = torch.empty((d, n), dtype=F64, device=Y.device).t()
+    _lib.check(_lib.lib().locus_hip_residual_dev(_p(Y), _p(A), _p(Zmu), _p(W2), _p(out), n, d,
+                                                 1 if to_residual else 0, _stream()))
+    return out
+
+
+def transpose(inp, rows, cols, out=None):
+    """Row-major [rows][cols] -> [cols][rows]."""
+    if out is None:
+        out = torch.empty((cols, rows), dtype=F64, device=inp.device)
+    _lib.check(_lib.lib().locus_hip_transpose_dev(_p(inp), _p(out), rows, cols, _stream()))
+    return out
+
+
+def gamma_rows(gam_plane, p, d, eps=None):
+    rs = torch.empty((p,), dtype=F64, device=gam_plane.device)
+    ent = torch.empty((p,), dtype=F64, device=gam_plane.device) if eps is not None else None
+    _lib.check(_lib.lib().locus_hip_gamma_rows_dev(_p(gam_plane), _p(rs), _p(ent), p, d,
+                                                   float(eps if eps is not None else 0.0),
+                                                   _stream()))
+    return rs, ent
+
+
+def state_cols(state, p, d, s2k=None, s2jk=None, nchunks=64):
+    nchunks = max(1, min(int(nchunks), p))
+    part = torch.empty((nchunks, 3, d), dtype=F64, device=state.device)
+    _lib.check(_lib.lib().locus_hip_state_cols_dev(_p(state), _p(s2k), _p(s2jk), _p(part), p, d,
+                                                   nchunks, _stream()))
+    return part.sum(dim=0)  # [3][d]
+
+
+def gemm(m, n, k, A, sa_m, sa_k, B, sb_k, sb_n, C, sc_m, sc_n, alpha=1.0, beta=0.0, sqA=False,
+         sqB=False):
+    _lib.check(_lib.lib().locus_hip_gemm_dev(m, n, k, float(alpha), _p(A), sa_m, sa_k, int(sqA),
+                                             _p(B), sb_k, sb_n, int(sqB), float(beta), _p(C), sc_m,
+                                             sc_n, _stream()))
+    return C
+
+
+def batch_update(state, lo, l1, fac, hinv, cstk, log_sig2_inv, nm1, probit, p, d):
+    _lib.check(_lib.lib().locus_hip_batch_update_dev(_p(state), _p(lo), _p(l1), _p(fac), _p(hinv),
+                                                     _p(cstk), float(log_sig2_inv), float(nm1),
+                                                     int(probit), p, d, _stream()))

@@ -1,0 +1,312 @@
+"""Identity-link CAVI driver with device-resident state (mirrors R/locus_core.R).
+
+Three layers:
+  IdentityHost    O(p + d) host arithmetic of one iteration on REDUCED statistics, plus
+                  the packed all-reduce -- no GPU needed (exercised under gloo on CPU);
+  IdentityEngine  the shard of the model that lives on one GPU: packed X, residual,
+                  state planes; runs the sweep + reductions through liblocus_hip;
+  locus_core_     numpy-facing wrapper with the reference's signature and return fields
+                  (R/locus_core.R:8-10, :242-252).
+"""
+import glob
+import os
+
+import numpy as np
+from scipy.special import digamma
+
+from . import elbo as E
+from . import update_vb as U
+from .comm import Comm
+
+EPS_SQRT = np.finfo(np.float64).eps ** 0.5  # R/locus_core.R:31
+EPS_MACH = np.finfo(np.float64).eps         # R/elbo.R:46
+
+
+class IdentityHost:
+    """Replicated / shard-local vector arithmetic of locus_core_ (R/locus_core.R:49-213).
+
+    Shard-local (length d_loc): eta, kappa, tau_vb, sig2_beta_vb and the column statistics.
+    Replicated (length p or scalar): a, b, lambda, nu, rs_gam, sum_gam, sum_tau_m2.
+    """
+
+    def __init__(self, n, p, d_total, hyper, tau_vb, sig2_beta_vb, comm=None):
+        self.n, self.p, self.d = int(n), int(p), int(d_total)
+        self.comm = comm or Comm()
+        self.a = np.broadcast_to(np.asarray(hyper["a"], dtype=np.float64), (p,)).copy()
+        self.b = np.broadcast_to(np.asarray(hyper["b"], dtype=np.float64), (p,)).copy()
+        self.eta = np.asarray(hyper["eta"], dtype=np.float64)      # shard-local
+        self.kappa = np.asarray(hyper["kappa"], dtype=np.float64)  # shard-local
+        self.lam, self.nu = float(hyper["lambda"]), float(hyper["nu"])
+        self.tau_vb = np.array(tau_vb, dtype=np.float64)
+        self.sig2_beta_vb = np.array(sig2_beta_vb, dtype=np.float64)
+        self.sig2_inv_vb = None
+        self.rs_gam = self.sum_gam = self.sum_tau_m2 = None
+        self.stats = None
+        self.a_vb = self.b_vb = self.om_vb = None
+
+    # -- exchange ------------------------------------------------------------
+    def _all_reduce(self, rs_gam_local, scalars):
+        """ONE all-reduce of [rowSums(gam) (p) | scalars]; returns (rs_gam, scalars) on host."""
+        import torch
+        tail = torch.tensor(list(scalars), dtype=torch.float64, device=rs_gam_local.device)
+        buf = torch.cat([rs_gam_local.reshape(-1), tail])
+        self.comm.all_reduce_sum_(buf)
+        h = buf.cpu().numpy()
+        return h[: self.p].copy(), h[self.p:].copy()
+
+    def set_initial(self, stats, rs_gam_local):
+        """R/locus_core.R:36-42: statistics of the initial gam_vb / mu_beta_vb."""
+        self.stats = np.asarray(stats, dtype=np.float64)
+        t_loc = float(self.tau_vb @ self.stats[1])
+        self.rs_gam, sc = self._all_reduce(rs_gam_local, [t_loc])
+        self.sum_gam = float(self.rs_gam.sum())
+        self.sum_tau_m2 = float(sc[0])
+
+    # -- top of the iteration: R/locus_core.R:57-84 ----------------------------
+    def begin_iteration(self, c=1.0):
+        n, d = self.n, self.d
+        cs_gam, cs_m2, cs_b2, rss = self.stats
+        digam_sum = digamma(c * (self.a + self.b + d) - 2 * c + 2)
+        lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam, c)
+        nu_vb = U.update_nu_vb_(self.nu, self.sum_tau_m2, c)
+        self.sig2_inv_vb = lambda_vb / nu_vb
+        eta_vb = U.update_eta_vb_(n, self.eta, cs_gam, c)
+        kappa_vb = U.update_kappa_vb_(n, self.kappa, rss, cs_m2, cs_b2, self.sig2_inv_vb, c)
+        self.tau_vb = eta_vb / kappa_vb
+        self.sig2_beta_vb = U.update_sig2_beta_vb_(n, self.sig2_inv_vb, self.tau_vb, c)
+        log_tau_vb = U.update_log_tau_vb_(eta_vb, kappa_vb)
+        log_sig2_inv_vb = U.update_log_sig2_inv_vb_(lambda_vb, nu_vb)
+        log_om_vb = U.update_log_om_vb(self.a, digam_sum, self.rs_gam, c)
+        log_1_min_om_vb = U.update_log_1_min_om_vb(self.b, d, digam_sum, self.rs_gam, c)
+        s2 = self.sig2_beta_vb
+        return dict(
+            lo=log_om_vb, l1=log_1_min_om_vb, log_sig2_inv_vb=float(log_sig2_inv_vb),
+            log_tau_vb=log_tau_vb, tau_vb=self.tau_vb, sig2_beta_vb=s2, c=float(c),
+            # per-response constants of the sweep kernel (src/coreLoop.cpp:34,42)
+            scale=c * s2 * self.tau_vb, hinv=1.0 / (2.0 * s2),
+            cst=-(log_tau_vb + log_sig2_inv_vb + np.log(s2)) / 2, s2k=s2)
+
+    # -- after the sweep: R/locus_core.R:95,169-197 and elbo_ :261-292 ---------
+    def end_iteration(self, stats, rs_gam_local, ent_local, c=1.0, with_elbo=True):
+        n, d = self.n, self.d
+        self.stats = np.asarray(stats, dtype=np.float64)
+        cs_gam, cs_m2, cs_b2, rss = self.stats
+        tau, s2, si = self.tau_vb, self.sig2_beta_vb, self.sig2_inv_vb
+        t_loc = float(tau @ cs_m2)
+        abc_loc = 0.0
+        if with_elbo:
+            eta_vb = U.update_eta_vb_(n, self.eta, cs_gam)
+            kappa_vb = U.update_kappa_vb_(n, self.kappa, rss, cs_m2, cs_b2, si)
+            log_tau_vb = digamma(eta_vb) - np.log(kappa_vb)
+            abc_loc = (E.e_y_(n, self.kappa, kappa_vb, log_tau_vb, cs_m2, si, tau)
+                       + E.e_beta_gamma_local_(cs_gam, cs_m2, ent_local, log_tau_vb, s2, si, tau)
+                       + E.e_tau_(self.eta, eta_vb, self.kappa, kappa_vb, log_tau_vb, tau))
+        self.rs_gam, sc = self._all_reduce(rs_gam_local, [t_loc, abc_loc])
+        self.sum_tau_m2 = float(sc[0])
+        self.a_vb = U.update_a_vb(self.a, self.rs_gam, c)
+        self.b_vb = U.update_b_vb(self.b, d, self.rs_gam, c)
+        self.om_vb = self.a_vb / (self.a_vb + self.b_vb)
+        self.sum_gam = float(self.rs_gam.sum())
+        if not with_elbo:
+            return None
+        lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam)
+        nu_vb = U.update_nu_vb_(self.nu, self.sum_tau_m2)
+        log_sig2_inv_vb = digamma(lambda_vb) - np.log(nu_vb)
+        log_om_vb = digamma(self.a_vb) - digamma(self.a_vb + self.b_vb)
+        log_1_min_om_vb = digamma(self.b_vb) - digamma(self.a_vb + self.b_vb)
+        return float(sc[1]
+                     + E.e_beta_gamma_global_(self.rs_gam, self.sum_gam, d, log_om_vb,
+                                              log_1_min_om_vb, log_sig2_inv_vb)
+                     + E.e_sig2_inv_(self.lam, lambda_vb, log_sig2_inv_vb, self.nu, nu_vb, si)
+                     + E.e_omega_(self.a, self.a_vb, self.b, self.b_vb, log_om_vb,
+                                  log_1_min_om_vb))
+
+
+class IdentityEngine:
+    """One GPU's shard of the identity-link model."""
+
+    def __init__(self, px, Y_dev, state, host, device, cfg=None):
+        import torch
+        from . import device as dv
+        self.torch, self.dv = torch, dv
+        self.px, self.Y, self.state, self.host, self.device = px, Y_dev, state, host, device
+        self.n, self.d_loc = Y_dev.shape
+        self.p = px.p
+        assert tuple(state.shape) == (3, self.p, self.d_loc)
+        self.sweeper = dv.Sweeper(px, self.d_loc, device, cfg=cfg)
+        self.stats = torch.empty((4, self.d_loc), dtype=torch.float64, device=device)
+        self.R = None
+
+    def _up(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    def initialise(self):
+        """beta = gam * mu, mat_x_m1 = X beta (fp64 MFMA GEMM), residual, statistics
+        (R/locus_core.R:36-42)."""
+        t, dv = self.torch, self.dv
+        n, p, d = self.n, self.p, self.d_loc
+        s2k = self._up(self.host.sig2_beta_vb)
+        cols = dv.state_cols(self.state, p, d, s2k=s2k)  # also writes the beta plane
+        M = t.empty((d, n), dtype=t.float64, device=self.device).t()
+        # M (n x d, col-major) = X (n x p) beta (p x d); X is read from its packed copy
+        dv.gemm(n, d, p, self.px.Xp, 1, self.px.ld, self.state[2], d, 1, M, 1, n)
+        self.R = dv.residual(self.Y, M)
+        del M
+        rss = (self.R * self.R).sum(dim=0)
+        rs_gam, _ = dv.gamma_rows(self.state[0], p, d)
+        stats = t.cat([cols, rss.reshape(1, d)], dim=0).cpu().numpy()
+        self.host.set_initial(stats, rs_gam)
+
+    def iterate(self, shuffled_ind, c=1.0, with_elbo=True):
+        """One pass of the loop body R/locus_core.R:49-211; returns the ELBO (or None)."""
+        dv = self.dv
+        prm = self.host.begin_iteration(c)
+        ind = shuffled_ind if self.torch.is_tensor(shuffled_ind) else self._up(shuffled_ind)
+        self.sweeper.identity(ind, self._up(prm["lo"]), self._up(prm["l1"]),
+                              self._up(prm["scale"]), self._up(prm["hinv"]), self._up(prm["cst"]),
+                              self._up(prm["s2k"]), c, self.R, self.state, self.stats)
+        rs_gam, ent = dv.gamma_rows(self.state[0], self.p, self.d_loc,
+                                    eps=EPS_MACH if with_elbo else None)
+        tail = ent.sum().reshape(1) if with_elbo else self.torch.zeros(1, dtype=self.torch.float64,
+                                                                      device=self.device)
+        h = self.torch.cat([self.stats.reshape(-1), tail]).cpu().numpy()
+        self.sweeper.status()
+        stats = h[:-1].reshape(4, self.d_loc)
+        return self.host.end_iteration(stats, rs_gam, float(h[-1]), c, with_elbo)
+
+    def download(self):
+        """gam_vb, mu_beta_vb, beta_vb (p x d_loc) and mat_x_m1 (n x d_loc) as numpy, R layout."""
+        dv = self.dv
+        out = {}
+        for name, q in (("gam_vb", 0), ("mu_beta_vb", 1), ("beta_vb", 2)):
+            out[name] = self.state[q].cpu().numpy().copy(order="F")
+        M = dv.residual(self.Y, self.R)  # M = Y - R
+        out["mat_x_m1"] = M.cpu().numpy().copy(order="F")
+        return out
+
+
+def checkpoint_(it, checkpoint_path, gam_vb_fn, converged, lb_new, lb_old, om_vb, rate=100):
+    """R/utils.R:316-336 (npz instead of RData): every `rate` iterations, keep the last two."""
+    if checkpoint_path is not None and it % rate == 0:
+        np.savez(os.path.join(checkpoint_path, f"tmp_output_it_{it}.npz"), gam_vb=gam_vb_fn(),
+                 converged=converged, it=it, lb_new=lb_new, diff_lb=abs(lb_new - lb_old),
+                 om_vb=om_vb)
+        old = os.path.join(checkpoint_path, f"tmp_output_it_{it - 2 * rate}.npz")
+        if os.path.exists(old):
+            os.remove(old)
+
+
+def checkpoint_clean_up_(checkpoint_path):  # R/utils.R:339-352
+    if checkpoint_path is not None:
+        for f in glob.glob(os.path.join(checkpoint_path, "tmp_output_it_*")):
+            os.remove(f)
+
+
+def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol, maxit,
+                anneal=None, verbose=False, batch="y", full_output=False, debug=True,
+                checkpoint_path=None, perm_fn=None, comm=None, device=None, trace=None):
+    """R/locus_core.R:8-255 on the GPU.  Y (n x d) must be centred and X (n x p) standardised.
+
+    `perm_fn(it)` supplies the sweep order of iteration `it` (float64, 0-based); by default
+    numpy draws it (R: sample(0:(p-1)), :88).  With a DistComm every rank passes the FULL
+    arrays and keeps only its response shard on its GPU; outputs are gathered on every rank.
+    """
+    import torch
+    from . import device as dv
+    dv.require_gpu()
+    if batch != "y":
+        raise NotImplementedError("only the 'y' scheme (coreLoop) is device-resident; "
+                                  "coreBatch is available as locus_amd.coreBatch")
+    comm = comm or Comm()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    Y = np.asarray(Y, dtype=np.float64)
+    X = np.asarray(X, dtype=np.float64)
+    n, d = Y.shape
+    p = X.shape[1]
+    k_lo, k_hi = comm.shard(d)
+    if perm_fn is None:
+        rng = np.random.default_rng(0)
+        perm_fn = lambda it: rng.permutation(p).astype(np.float64)  # noqa: E731
+
+    hyper_loc = dict(list_hyper)
+    hyper_loc["eta"] = np.broadcast_to(np.asarray(list_hyper["eta"], dtype=np.float64),
+                                       (d,))[k_lo:k_hi]
+    hyper_loc["kappa"] = np.broadcast_to(np.asarray(list_hyper["kappa"], dtype=np.float64),
+                                         (d,))[k_lo:k_hi]
+    host = IdentityHost(n, p, d, hyper_loc, np.asarray(tau_vb)[k_lo:k_hi],
+                        np.asarray(sig2_beta_vb)[k_lo:k_hi], comm)
+    px = dv.PackedX(dv.to_device_colmajor(X, device))
+    Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
+    state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)
+    state[0] = torch.from_numpy(np.ascontiguousarray(np.asarray(gam_vb)[:, k_lo:k_hi])).to(device)
+    state[1] = torch.from_numpy(np.ascontiguousarray(np.asarray(mu_beta_vb)[:, k_lo:k_hi])).to(device)
+    eng = IdentityEngine(px, Y_dev, state, host, device)
+    eng.initialise()
+
+    if anneal is None:
+        annealing, c, ladder = False, 1.0, None
+    else:
+        annealing, ladder = True, U.get_annealing_ladder_(anneal)
+        c = float(ladder[0])
+
+    converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
+    while (not converged) and it < maxit:                                # :49
+        lb_old = lb_new
+        it += 1
+        if verbose and (it == 1 or it % 5 == 0):
+            print(f"Iteration {it}... ")
+        ind = np.ascontiguousarray(perm_fn(it), dtype=np.float64)
+        lb = eng.iterate(ind, c, with_elbo=not annealing)
+        if annealing:                                                    # :177-190
+            c = float(ladder[it]) if it < len(ladder) else 1.0
+            if np.isclose(c, 1.0, rtol=1.5e-8, atol=0):
+                annealing = False
+        else:
+            lb_new = lb
+            if trace is not None:
+                trace.append((it, lb_new))
+            if verbose and (it == 1 or it % 5 == 0):
+                print(f"ELBO = {lb_new}\n")
+            if debug and lb_new + EPS_SQRT < lb_old:                     # :202-203
+                raise RuntimeError("ELBO not increasing monotonically. Exit. ")
+            converged = abs(lb_new - lb_old) < tol                       # :205
+            checkpoint_(it, checkpoint_path, lambda: _gather(comm, eng.download()["gam_vb"], d),
+                        converged, lb_new, lb_old, host.om_vb)
+    checkpoint_clean_up_(checkpoint_path)
+    if verbose and not converged:
+        print("Maximal number of iterations reached before convergence. Exit.")
+
+    loc = eng.download()
+    out = dict(beta_vb=_gather(comm, loc["beta_vb"], d), gam_vb=_gather(comm, loc["gam_vb"], d),
+               om_vb=host.om_vb, converged=converged, it=it, lb_opt=lb_new,
+               diff_lb=abs(lb_new - lb_old), annealing=False if anneal is None else anneal[0])
+    if full_output:                                                      # :242-247
+        out.update(mu_beta_vb=_gather(comm, loc["mu_beta_vb"], d),
+                   mat_x_m1=_gather(comm, loc["mat_x_m1"], d),
+                   sig2_beta_vb=_gather_vec(comm, host.sig2_beta_vb, d),
+                   tau_vb=_gather_vec(comm, host.tau_vb, d), sig2_inv_vb=host.sig2_inv_vb,
+                   a_vb=host.a_vb, b_vb=host.b_vb, sum_gam=host.sum_gam)
+    return out
+
+
+def _gather(comm, local, d):
+    """Concatenate the response shards (columns) of every rank, on every rank."""
+    if comm.world == 1:
+        return local
+    import torch
+    import torch.distributed as dist
+    rows = local.shape[0]
+    full = np.zeros((rows, d), order="F")
+    k_lo, k_hi = comm.shard(d)
+    full[:, k_lo:k_hi] = local
+    t = torch.from_numpy(np.ascontiguousarray(full.T))
+    if dist.get_backend(comm.group) == "nccl":
+        t = t.cuda()
+    comm.all_reduce_sum_(t)
+    return np.asfortranarray(t.cpu().numpy().T)
+
+
+def _gather_vec(comm, local, d):
+    if comm.world == 1:
+        return local
+    return _gather(comm, np.asarray(local, dtype=np.float64).reshape(1, -1), d).reshape(-1)

@@ -1,0 +1,124 @@
+"""Data preparation, default hyper-parameters and default initial values
+(mirrors the parts of R/prepare_locus.R and R/set_hyper_init.R the hot path depends on).
+
+R's RNG is replaced by numpy's Generator: for a given seed the draws differ from R's,
+their distributions are the reference's.
+"""
+import numpy as np
+from scipy.stats import norm
+
+
+def prepare_data_(Y, X, link="identity"):
+    """R/prepare_locus.R:109-141: scale(X) (centre, sd with n-1), drop constant and duplicated
+    columns, centre Y (identity) / subtract 1/2 (logit).  Returns (Y, X, bool_rmvd_x)."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        Xs = (X - X.mean(axis=0)) / X.std(axis=0, ddof=1)
+    bool_cst = np.isnan(Xs.sum(axis=0))                       # rm_constant_, R/utils.R:244-271
+    Xs = Xs[:, ~bool_cst]
+    _, first = np.unique(Xs, axis=1, return_index=True)       # rm_collinear_, R/utils.R:273-311
+    bool_coll = np.ones(Xs.shape[1], dtype=bool)
+    bool_coll[first] = False
+    Xs = Xs[:, ~bool_coll]
+    bool_rmvd_x = bool_cst.copy()
+    bool_rmvd_x[~bool_cst] = bool_coll
+    if Xs.shape[1] < 1:
+        raise ValueError("There must be at least 1 non-constant candidate predictor stored in X.")
+    if link == "identity":
+        Y = Y - Y.mean(axis=0)
+    elif link == "logit":
+        Y = Y - 0.5
+    return np.asfortranarray(Y), np.asfortranarray(Xs), bool_rmvd_x
+
+
+def convert_p0_av_(p0_av, p):
+    """R/prepare_locus.R:155-214 (scalar or length-p p0_av, no blocks)."""
+    eps = np.finfo(np.float64).eps ** 0.5
+    p0_av = np.atleast_1d(np.asarray(p0_av, dtype=np.float64))
+    if p0_av.size == 1:
+        v = float(p0_av[0])
+        if v / p < eps:
+            raise ValueError("invalid p0_av: the prior sparsity level p0_av / p must be > 0")
+        if v / p > 0.95:
+            raise ValueError("invalid p0_av: induces a non-sparse formulation")
+        return v
+    if p0_av.size != p:
+        raise ValueError("p0_av must have length 1 or p")
+    if (p0_av < eps).any() or (p0_av > 1 - eps).any():
+        raise ValueError("All entries of p0_av must lie strictly between 0 and 1")
+    return p0_av * p
+
+
+def auto_set_hyper_(Y, p, p_star, q=None, link="identity", struct=False):
+    """R/set_hyper_init.R:321-419 (no groups, no mix)."""
+    d = Y.shape[1]
+    h = dict(d_hyper=d, p_hyper=p, q_hyper=q, link_hyper=link)
+    h["lambda"] = 1e-2
+    h["nu"] = 1.0
+    if link == "identity":
+        eta = 1.0 / np.median(Y.var(axis=0, ddof=1))
+        if not np.isfinite(eta):
+            eta = 1e3
+        h["eta"] = np.full(d, eta)
+        h["kappa"] = np.ones(d)
+    else:
+        h["eta"] = h["kappa"] = None
+    a = np.ones(p)
+    b = np.broadcast_to(d * (p - np.asarray(p_star, dtype=np.float64)) / p_star, (p,)).copy()
+    if (a <= 0).any() or (b <= 0).any():
+        raise ValueError("hyper-parameters a and b must be positive")
+    if struct:
+        h["s02"] = 0.1
+        h["m0"] = -norm.ppf(b / (a + b)) * np.sqrt(1 + h["s02"])
+        h["a"] = h["b"] = None
+    else:
+        h["a"], h["b"] = a, b
+        h["m0"] = h["s02"] = None
+    if q is not None:
+        h["phi"] = np.ones(q)
+        h["xi"] = np.ones(q)
+    else:
+        h["phi"] = h["xi"] = None
+    return h
+
+
+def auto_set_init_(Y, p, p_star, q=None, user_seed=None, link="identity"):
+    """R/set_hyper_init.R:750-874 (no groups, no mix)."""
+    d = Y.shape[1]
+    rng = np.random.default_rng(user_seed)
+    shape2 = d * (p - np.asarray(p_star, dtype=np.float64)) / p_star
+    if np.ndim(shape2) == 0:
+        gam_vb = rng.beta(1.0, float(shape2), size=(p, d))
+    else:
+        gam_vb = rng.beta(1.0, np.asarray(shape2)[:, None], size=(p, d))
+    mu_beta_vb = rng.normal(size=(p, d))
+    sig2_inv_vb = 1e-2
+    init = dict(d_init=d, p_init=p, q_init=q, link_init=link, gam_vb=np.asfortranarray(gam_vb),
+                mu_beta_vb=np.asfortranarray(mu_beta_vb), sig2_inv_vb=sig2_inv_vb)
+    if link == "identity":
+        tau = 1.0 / np.median(Y.var(axis=0, ddof=1))
+        if not np.isfinite(tau):
+            tau = 1e3
+        tau_vb = np.full(d, tau)
+        init["tau_vb"] = tau_vb
+        # 1 / rgamma(d, shape = 2, rate = 1 / (sig2_inv_vb * tau_vb))
+        init["sig2_beta_vb"] = 1.0 / rng.gamma(2.0, sig2_inv_vb * tau_vb, size=d)
+    elif link == "logit":
+        init["tau_vb"] = None
+        init["sig2_beta_vb"] = np.asfortranarray(1.0 / rng.gamma(2.0, sig2_inv_vb, size=(p, d)))
+    else:  # probit
+        init["tau_vb"] = None
+        init["sig2_beta_vb"] = float(1.0 / rng.gamma(2.0, sig2_inv_vb))
+    init["alpha_vb"] = init["sig2_alpha_vb"] = None
+    return init
+
+
+def add_intercept_(n, d, list_hyper, list_init, link):
+    """R/locus.R:381-399 (Z = NULL): intercept column with a vague prior for logit/probit."""
+    Z = np.ones((n, 1), order="F")
+    list_hyper["phi"] = np.array([1e-3])
+    list_hyper["xi"] = np.array([1e-3])
+    list_init["alpha_vb"] = np.zeros((1, d))
+    list_init["sig2_alpha_vb"] = np.array([1.0]) if link == "probit" else np.ones((1, d))
+    return Z

@@ -1,0 +1,63 @@
+"""Times the identity (or logit) sweep kernel for explicit geometries on one GPU.
+usage: python scripts/perf_sweep.py n p d [logit] cfg1 cfg2 ...   (cfg = NPL,C,S,G or auto)"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from locus_amd import device as dv, _lib
+
+def main():
+    n, p, d = map(int, sys.argv[1:4])
+    rest = sys.argv[4:]
+    logit = False
+    if rest and rest[0] == "logit":
+        logit = True; rest = rest[1:]
+    nsteps = p
+    cfgs = rest or ["auto"]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    X = torch.bernoulli(torch.full((p, n), 0.25, device=dev, dtype=torch.float64), generator=g) + \
+        torch.bernoulli(torch.full((p, n), 0.25, device=dev, dtype=torch.float64), generator=g)
+    X = (X - X.mean(dim=1, keepdim=True)) / X.std(dim=1, keepdim=True).clamp_min(1e-3)
+    Xc = X.t()  # n x p column-major storage
+    px = dv.PackedX(Xc)
+    del X, Xc
+    state = torch.empty((3, p, d), device=dev, dtype=torch.float64)
+    state[0].uniform_(0, 1, generator=g); state[0].pow_(8.0)
+    state[1].normal_(0, 0.3, generator=g)
+    state[2] = state[0] * state[1]
+    R0 = torch.randn((d, n), device=dev, dtype=torch.float64, generator=g) * 0.7
+    lo = torch.full((p,), -3.0, device=dev, dtype=torch.float64)
+    l1 = torch.full((p,), -0.05, device=dev, dtype=torch.float64)
+    tau = torch.full((d,), 2.0, device=dev, dtype=torch.float64)
+    s2k = 1.0 / ((n - 1 + 0.7) * tau)
+    scale = s2k * tau; hinv = 1.0 / (2 * s2k); cst = -(tau.log() + np.log(0.7) + s2k.log()) / 2
+    stats = torch.empty((4, d), device=dev, dtype=torch.float64)
+    if logit:
+        W2 = (torch.rand((d, n), device=dev, dtype=torch.float64, generator=g) * 0.2 + 0.2).t()
+        s2 = torch.full((p, d), 1.0 / (n * 0.3), device=dev, dtype=torch.float64)
+        xwx = torch.full((p, d), n * 0.3, device=dev, dtype=torch.float64)
+    for cs in cfgs:
+        cfg = None if cs == "auto" else tuple(map(int, cs.split(",")))
+        sw = dv.Sweeper(px, d, dev, cfg=cfg)
+        times = []
+        for it in range(4):
+            perm = torch.randperm(p, device=dev, generator=g).to(torch.float64)
+            R = R0.clone().t()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if logit:
+                sw.logit(perm, lo, l1, s2, xwx, W2, 0.1, R, state, stats, nsteps)
+            else:
+                sw.identity(perm, lo, l1, scale, hinv, cst, s2k, 1.0, R, state, stats, nsteps)
+            e1.record(); torch.cuda.synchronize()
+            sw.status()
+            times.append(e0.elapsed_time(e1))
+        t = min(times[1:])
+        cfg_used = (_lib.ctypes.c_int32 * 4)()
+        _lib.lib().locus_hip_sweep_config(n, d, int(logit), cfg_used)
+        upd = nsteps * d / (t * 1e-3)
+        print(f"cfg={cs:12s} auto={list(cfg_used)} ms={t:9.3f} (all {[round(x,2) for x in times]}) "
+              f"updates/s={upd:.3e} fp64_TF={(upd*(4*n))/1e12:.2f} algGB/s={upd*(16*n+8*n/d+32)/1e9:.0f}",
+              flush=True)
+
+main()

@@ -1,0 +1,77 @@
+"""GPU parity of the device-resident identity driver (locus_amd.locus_core.locus_core_)
+against the numpy restatement of R/locus_core.R (oracle.ref_driver.locus_core_), on the
+BASELINE config C1 (n=200, p=500, d=20, p0_av=15) and identical sweep orders."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n=200, p=500, d=20, p0=15, seed=123):
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_
+    from locus_amd.simulate import simulate
+    sim = simulate(n, p, d, p0, seed=seed)
+    hyper = auto_set_hyper_(sim["Y"], p, p0)
+    init = auto_set_init_(sim["Y"], p, p0, user_seed=seed)
+    perms = np.random.default_rng(1)
+    table = {}
+
+    def perm_fn(it):
+        if it not in table:
+            table[it] = perms.permutation(p).astype(np.float64)
+        return table[it]
+    return sim, hyper, init, perm_fn
+
+
+@pytest.mark.parametrize("maxit", [1, 5])
+def test_identity_fixed_iterations(oracle, hip, maxit):
+    from oracle import ref_driver
+    from locus_amd.locus_core import locus_core_
+    sim, hyper, init, perm_fn = _setup()
+    kw = dict(tol=1e-30, maxit=maxit, perm_fn=perm_fn, full_output=True)
+    ref = ref_driver.locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                                 init["sig2_beta_vb"], init["tau_vb"], **kw)
+    got = locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                      init["sig2_beta_vb"], init["tau_vb"], **kw)
+    assert got["it"] == ref["it"] == maxit
+    for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    np.testing.assert_allclose(got["om_vb"], ref["om_vb"], rtol=1e-9)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])  # north_star: ELBO 1e-8
+    assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+
+
+def test_identity_to_convergence_recovers_actives(oracle, hip):
+    from oracle import ref_driver
+    from locus_amd.locus_core import locus_core_
+    sim, hyper, init, perm_fn = _setup()
+    tr_ref, tr_got = [], []
+    ref = ref_driver.locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                                 init["sig2_beta_vb"], init["tau_vb"], tol=0.1, maxit=1000,
+                                 perm_fn=perm_fn, trace=tr_ref)
+    got = locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                      init["sig2_beta_vb"], init["tau_vb"], tol=0.1, maxit=1000, perm_fn=perm_fn,
+                      trace=tr_got)
+    assert got["converged"] and ref["converged"] and got["it"] == ref["it"]
+    lb_r = np.array([x[1] for x in tr_ref]); lb_g = np.array([x[1] for x in tr_got])
+    np.testing.assert_allclose(lb_g, lb_r, rtol=1e-8)
+    assert np.all(np.diff(lb_g) > -1.49e-8)  # ELBO monotone (R/locus_core.R:202-203)
+    np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+    # the simulated active SNPs are found (each is associated with >= 1 response)
+    found = (got["gam_vb"] > 0.5).any(axis=1)
+    assert found[sim["ind_p0"]].mean() >= 0.8
+    assert found.sum() <= 2 * len(sim["ind_p0"])
+
+
+def test_identity_annealing(oracle, hip):
+    from oracle import ref_driver
+    from locus_amd.locus_core import locus_core_
+    sim, hyper, init, perm_fn = _setup(n=100, p=80, d=6, p0=5)
+    kw = dict(tol=1e-30, maxit=7, perm_fn=perm_fn, anneal=(1, 2.0, 4), full_output=True)
+    ref = ref_driver.locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                                 init["sig2_beta_vb"], init["tau_vb"], **kw)
+    got = locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                      init["sig2_beta_vb"], init["tau_vb"], **kw)
+    np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], rtol=1e-9, atol=1e-12)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
