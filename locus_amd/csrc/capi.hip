@@ -48,7 +48,7 @@ int download(double* host, const DevMem& m, size_t count)
 int check_dims(int64_t n, int64_t p, int64_t d)
 {
     LOCUS_REQUIRE(n >= 1 && p >= 1 && d >= 1, "n, p and d must be >= 1");
-    LOCUS_REQUIRE(n <= 8192, "n > 8192 rows is not supported by the register-resident sweep");
+    LOCUS_REQUIRE(n <= 4096, "n > 4096 rows is not supported by the register-resident sweep");
     LOCUS_REQUIRE(p < (1ll << 31) && d < (1ll << 31) && n * d < (1ll << 40) && p * d < (1ll << 40),
                   "problem too large");
     return 0;

@@ -125,7 +125,7 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
         }
     }
     if (bc.NPL == 0) {
-        set_error("sweep: n is too large for the register-resident kernel (n <= 8192)");
+        set_error("sweep: n is too large for the register-resident kernel (n <= 4096)");
         return LOCUS_HIP_EUNSUPPORTED;
     }
     *out = bc;

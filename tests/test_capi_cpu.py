@@ -1,0 +1,87 @@
+"""CPU checks of the boundary: liblocus_hip.so loads, exports every symbol the header
+declares, and the argument validation that runs before any GPU work behaves."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "locus_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(locus_hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    from locus_amd import _lib
+    h = _lib.lib()
+    names = _declared()
+    assert len(names) >= 20
+    for nm in names:
+        assert hasattr(h, nm), f"{nm} declared in include/locus_hip.h but not exported"
+        assert nm in _lib.SIGNATURES, f"{nm} has no ctypes signature in locus_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert h.locus_hip_version() >= 100
+    assert h.locus_hip_packed_ld(1000) == 1024 and h.locus_hip_packed_ld(128) == 128
+
+
+def test_sweep_args_struct_matches_header():
+    from locus_amd import _lib
+    # 3 int64 + 5 ptr + 4 ptr + double + 3 ptr + double + 3 ptr + ptr + 2 int64 + 4 int32
+    assert ctypes.sizeof(_lib.SweepArgs) == 8 * (3 + 5 + 4 + 1 + 3 + 1 + 3 + 1 + 2) + 16
+
+
+@pytest.mark.parametrize("n,d", [(200, 20), (1000, 1000), (1000, 1250), (1000, 10000),
+                                 (2000, 500), (1000, 2000), (64, 1), (4096, 8)])
+@pytest.mark.parametrize("logit", [0, 1])
+def test_geometry_chooser(n, d, logit):
+    from locus_amd import _lib
+    cfg = (ctypes.c_int32 * 4)()
+    _lib.check(_lib.lib().locus_hip_sweep_config(n, d, logit, cfg))
+    npl, c, s, g = list(cfg)
+    assert npl in (2, 4, 8, 16) and 64 * npl * s >= n and 64 * s * g <= 1024
+    assert 2 * npl * c * (2 if logit else 1) <= 170  # residual fits the 256-VGPR budget
+    assert g >= (npl + 3) // 4                        # <= 2 staging pieces per thread
+
+
+def test_rejects_bad_arguments_before_touching_the_gpu():
+    import locus_amd
+    from locus_amd._lib import LocusHipError
+    from helpers import call_variant, inputs_for
+    inp = inputs_for("identity", 50, 8, 2, seed=0)
+    inp["shuffled_ind"] = np.array([0, 1, 2, 3, 4, 5, 6, 9], dtype=np.float64)  # out of range
+    with pytest.raises(LocusHipError) as ei:
+        call_variant(locus_amd.core, "identity", inp)
+    assert ei.value.code == -3
+    inp = inputs_for("identity", 50, 8, 2, seed=0)
+    with pytest.raises(ValueError):
+        locus_amd.coreLoop(inp["X"], inp["Y"], inp["gam_vb"][:, :1], inp["log_om_vb"],
+                           inp["log_1_min_om_vb"], 0.0, inp["log_tau_vb"], inp["beta_vb"],
+                           inp["mat_x_m1"], inp["mu_beta_vb"], inp["sig2_beta_vb"], inp["tau_vb"],
+                           inp["shuffled_ind"])
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product must fail loudly, not fall back to a CPU path."""
+    import locus_amd
+    from locus_amd import _lib
+    from locus_amd._lib import LocusHipError
+    from helpers import call_variant, inputs_for
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(LocusHipError):
+        call_variant(locus_amd.core, "identity", inputs_for("identity", 50, 8, 2, seed=0))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "locus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "liblocus_oracle" not in txt, f
