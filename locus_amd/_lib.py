@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblocus_hip.so")
+LIB_PATH = os.environ.get("LOCUS_HIP_LIB", os.path.join(_HERE, "liblocus_hip.so"))
 
 c_double_p = ctypes.c_void_p
 _i64 = ctypes.c_int64

@@ -48,7 +48,7 @@ int download(double* host, const DevMem& m, size_t count)
 int check_dims(int64_t n, int64_t p, int64_t d)
 {
     LOCUS_REQUIRE(n >= 1 && p >= 1 && d >= 1, "n, p and d must be >= 1");
-    LOCUS_REQUIRE(n <= 4096, "n > 4096 rows is not supported by the register-resident sweep");
+    LOCUS_REQUIRE(n <= 2048, "n > 2048 rows is not supported by the register-resident sweep");
     LOCUS_REQUIRE(p < (1ll << 31) && d < (1ll << 31) && n * d < (1ll << 40) && p * d < (1ll << 40),
                   "problem too large");
     return 0;
@@ -77,8 +77,8 @@ int check_permutation(const double* ind, int64_t p)
 
 size_t workspace_bytes(int64_t p)
 {
-    const size_t nsteps_pad = ((size_t)p + 3) / 4 * 4;
-    size_t b = sizeof(StepRec) * (nsteps_pad + 8);  // step records
+    const size_t nsteps_pad = ((size_t)p + 11) / 12 * 12;
+    size_t b = sizeof(StepRec) * (nsteps_pad + 16);  // step records
     b = (b + 255) / 256 * 256;
     b += sizeof(int) * (size_t)p;  // visited[]
     b = (b + 255) / 256 * 256;
@@ -94,11 +94,11 @@ struct WsView {
 
 WsView carve(void* ws, int64_t p)
 {
-    const size_t nsteps_pad = ((size_t)p + 3) / 4 * 4;
+    const size_t nsteps_pad = ((size_t)p + 11) / 12 * 12;
     char* c = static_cast<char*>(ws);
     WsView v;
     v.steps = reinterpret_cast<StepRec*>(c);
-    size_t b = sizeof(StepRec) * (nsteps_pad + 8);
+    size_t b = sizeof(StepRec) * (nsteps_pad + 16);
     b = (b + 255) / 256 * 256;
     v.visited = reinterpret_cast<int*>(c + b);
     b += sizeof(int) * (size_t)p;
@@ -134,9 +134,9 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
     }
 
     WsView ws = carve(a->workspace, a->p);
-    const int nsteps_pad = (int)((nsteps + 3) / 4 * 4);
+    const int nsteps_pad = (int)((nsteps + 11) / 12 * 12);
     rc = build_steps(a->shuffled_ind, a->lo, a->l1, a->xtx, ws.steps, ws.visited, ws.err, (int)a->p,
-                     (int)nsteps, nsteps_pad + 8, st);
+                     (int)nsteps, nsteps_pad + 16, st);
     if (rc) return rc;
 
     SweepParams prm;

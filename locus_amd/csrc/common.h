@@ -49,9 +49,9 @@ struct SweepParams {
     int S, G;           // waves per column (row slices), column groups per workgroup
     int npad;           // 64 * NPL * S  (>= ld)
     int nsteps;         // covariates visited this sweep (== p for a full sweep)
-    int nsteps_pad;     // nsteps rounded up to the unroll depth (4)
+    int nsteps_pad;     // nsteps rounded up to a multiple of 12 (every prefetch depth)
     const double* Xp;   // [p][ld]   packed, zero padded columns of X
-    const StepRec* steps;  // [nsteps_pad + 8]  (pad entries: j = 0, lod = xtx = 0)
+    const StepRec* steps;  // [nsteps_pad + 16]  (pad entries: j = 0, lod = xtx = 0)
     const int* err;        // device error word written by the prologue (non-zero => abort)
     // identity family: per-response constants
     const double* scale;  // [d]  (c * sig2_beta_k) * tau_k      (probit: sig2_beta)

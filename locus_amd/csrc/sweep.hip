@@ -35,7 +35,10 @@ static int max_c(int npl, bool logit)
 
 static int vgpr_estimate(int npl, int c, bool logit)
 {
-    return 2 * npl * c * (logit ? 2 : 1) + 8 + 90;
+    // keep in step with sweep_depth() / sweep_max_threads() of sweep_kernel.h
+    const int regs = 2 * npl * c * (logit ? 2 : 1);
+    const int depth = regs <= 64 ? 6 : (regs <= 112 ? 4 : 2);
+    return regs + 8 * depth + 90;
 }
 
 size_t sweep_lds_bytes(const SweepConfig& cfg)
@@ -125,7 +128,7 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
         }
     }
     if (bc.NPL == 0) {
-        set_error("sweep: n is too large for the register-resident kernel (n <= 4096)");
+        set_error("sweep: n is too large for the register-resident kernel (n <= 2048)");
         return LOCUS_HIP_EUNSUPPORTED;
     }
     *out = bc;

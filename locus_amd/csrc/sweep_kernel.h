@@ -116,11 +116,21 @@ __device__ __forceinline__ double reduce_merge(const double (&v)[C], int sub)
     return U;
 }
 
-#ifndef LOCUS_UNROLL
-#define LOCUS_UNROLL 4
-#endif
-constexpr int kUnroll = LOCUS_UNROLL;  // depth of the per-response state prefetch ring
 constexpr int kMaxPieces = 2;  // 16-byte X pieces a thread stages per column (G >= NPL/4)
+constexpr int kStepPad = 12;   // nsteps is padded to a multiple of every prefetch depth
+constexpr int kStepTail = 16;  // readable step records past nsteps_pad
+
+// Prefetch depth D (= unroll factor of the main loop).  Every global load of the loop is a
+// prefetch for step i + D and the loads are consumed in the order they were issued, because
+// vmcnt retires in order: a wait for a young load would also wait for every older one, so a
+// short-distance load behind a long-distance HBM miss would serialise the sweep on HBM
+// latency.  Small geometries (latency regime) have the registers for a deep ring.
+template <int NPL, int C, bool LOGIT>
+constexpr int sweep_depth()
+{
+    constexpr int regs = 2 * NPL * C * (LOGIT ? 2 : 1);
+    return regs <= 64 ? 6 : (regs <= 112 ? 4 : 2);
+}
 
 // Every instantiation is built for <= 256 VGPRs (two waves per SIMD): arithmetic
 // VGPRs stop at 256 on gfx950, anything above lives in AGPRs behind
@@ -128,9 +138,33 @@ constexpr int kMaxPieces = 2;  // 16-byte X pieces a thread stages per column (G
 template <int NPL, int C, bool LOGIT>
 constexpr int sweep_max_threads()
 {
-    constexpr int est = 2 * NPL * C * (LOGIT ? 2 : 1) + 4 * kMaxPieces + 90;
+    constexpr int est = 2 * NPL * C * (LOGIT ? 2 : 1) +
+                        4 * kMaxPieces * sweep_depth<NPL, C, LOGIT>() + 90;
     return est <= 128 ? 1024 : 512;
 }
+
+// Step records are read-only for the kernel and uniform per step: reading them through the
+// constant address space makes them scalar (s_load, lgkmcnt) instead of vector loads that
+// would queue behind the state prefetches in vmcnt order.
+typedef const StepRec __attribute__((address_space(4))) * StepPtr;
+
+// Diagnostic build only (-DLOCUS_STAMPS, `make diag`): per-phase cycle sums of wave 0 of every
+// workgroup (s_memtime), written to g_sweep_stamps.  No stamp executes in the product build.
+#ifdef LOCUS_STAMPS
+constexpr int kStampSlots = 8;
+__device__ unsigned long long g_sweep_stamps[kStampSlots * 4096];
+#define LOCUS_STAMP(k)                                                                   \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        unsigned long long t_;                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+        tacc[k] += t_ - tprev;                                                           \
+        tprev = t_;                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define LOCUS_STAMP(k) do { } while (0)
+#endif
 
 template <int NPL, int C, bool LOGIT>
 __global__ void __launch_bounds__((sweep_max_threads<NPL, C, LOGIT>()))
@@ -237,51 +271,65 @@ sweep_kernel(const SweepParams P)
     const size_t pd = (size_t)P.p * d;
     const int kls = cvalid ? kl : 0;  // safe column for speculative state loads
 
+    constexpr int D = sweep_depth<NPL, C, LOGIT>();
+    const StepPtr steps = (StepPtr)(unsigned long long)P.steps;
+
     // ---- X staging: zero the ring once, stage columns of steps 0 and 1 -------
     const int npieces = P.ld >> 1;  // 16-byte pieces per column
     for (int e = tid; e < 3 * P.npad; e += nthr) xring[e] = 0.0;
     __syncthreads();
 #pragma unroll
     for (int pre = 0; pre < 2; ++pre) {
-        const double2* src =
-            reinterpret_cast<const double2*>(P.Xp + (size_t)P.steps[pre].j * P.ld);
+        const double2* src = reinterpret_cast<const double2*>(P.Xp + (size_t)steps[pre].j * P.ld);
         double2* dst = reinterpret_cast<double2*>(xring + pre * P.npad);
         for (int e = tid; e < npieces; e += nthr) dst[e] = src[e];
     }
-    // ---- per-response state prefetch ring (steps 0..3) ------------------------
-    double bo_ring[kUnroll];
-    double s2_ring[LOGIT ? kUnroll : 1];
-    double xw_ring[LOGIT ? kUnroll : 1];
+    // ---- prefetch rings: X pieces of steps 2..D+1, per-response state of steps 0..D-1 ----
+    double2 xq[D][kMaxPieces];
+    double bo_ring[D];
+    double s2_ring[LOGIT ? D : 1];
+    double xw_ring[LOGIT ? D : 1];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-        const size_t off = (size_t)P.steps[u].j * d + kls;
+    for (int u = 0; u < D; ++u) {
+        const size_t off = (size_t)steps[u].j * d + kls;
         bo_ring[u] = P.state[2 * pd + off];
         if constexpr (LOGIT) {
             s2_ring[u] = P.s2[off];
             xw_ring[u] = P.xwx[off];
         }
+        // slot (u + 2) % D holds the column of step u + 2
+        const double2* src =
+            reinterpret_cast<const double2*>(P.Xp + (size_t)steps[u + 2].j * P.ld);
+#pragma unroll
+        for (int q = 0; q < kMaxPieces; ++q) {
+            const int e = tid + q * nthr;
+            xq[(u + 2) % D][q] = (e < npieces) ? src[e] : make_double2(0.0, 0.0);
+        }
     }
     __syncthreads();
 
     int slot = 0;  // ring slot of the current step's column (i % 3)
-    for (int i0 = 0; i0 < P.nsteps_pad; i0 += kUnroll) {
+    double nx_lod = steps[0].lod, nx_xtx = steps[0].xtx;
+    int nx_j = steps[0].j, nx_jd = steps[D].j, nx_jx = steps[2 + D].j;
+#ifdef LOCUS_STAMPS
+    unsigned long long tacc[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
+    for (int i0 = 0; i0 < P.nsteps_pad; i0 += D) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < D; ++u) {
             const int i = i0 + u;
             const bool act = i < P.nsteps;  // pad steps are no-ops
-            const StepRec st = P.steps[i];
-
-            // (1) issue the global loads of column i+2 (written to LDS at the end)
-            double2 xpre[kMaxPieces];
-            {
-                const double2* src =
-                    reinterpret_cast<const double2*>(P.Xp + (size_t)P.steps[i + 2].j * P.ld);
-#pragma unroll
-                for (int q = 0; q < kMaxPieces; ++q) {
-                    const int e = tid + q * nthr;
-                    xpre[q] = (e < npieces) ? src[e] : make_double2(0.0, 0.0);
-                }
-            }
+            // step records are read one step ahead (scalar loads issued here are consumed in
+            // step i + 1): an in-order wave would otherwise sit on their latency at every use
+            const double st_lod = nx_lod, st_xtx = nx_xtx;
+            const int st_j = nx_j, st_jd = nx_jd, st_jx = nx_jx;
+            nx_lod = steps[i + 1].lod;
+            nx_xtx = steps[i + 1].xtx;
+            nx_j = steps[i + 1].j;
+            nx_jd = steps[i + 1 + D].j;
+            nx_jx = steps[i + 3 + D].j;
 
             // (2)+(3) partial dot products X_j' R_c over this wave's row slice
             const double2* xs =
@@ -312,7 +360,9 @@ sweep_kernel(const SweepParams P)
 #pragma unroll
                 for (int c = 0; c < C; ++c) pd0[c] += pd1[c];
             }
+            LOCUS_STAMP(0);  // LDS read of X + dot products
             double U = reduce_merge<C>(pd0, sub);
+            LOCUS_STAMP(1);  // wave reduction
 
             // (4) cross-wave (row-slice) reduction through LDS; the barrier also
             //     publishes the X column staged at the end of the previous step
@@ -329,6 +379,7 @@ sweep_kernel(const SweepParams P)
                 __syncthreads();
             }
 
+            LOCUS_STAMP(2);  // barrier (+ cross-wave partials)
             // (5) element-wise update, one response per lane
             const double bo = bo_ring[u];
             double m, a, s2v;
@@ -336,22 +387,23 @@ sweep_kernel(const SweepParams P)
                 s2v = s2_ring[u];
                 const double dot = fma(xw_ring[u], bo, U);
                 m = s2v * dot;                                                // coreLoop.cpp:121
-                a = st.lod - P.half_lsi - m * m / (2.0 * s2v) - log(s2v) / 2.0;  // :123-125
+                a = st_lod - P.half_lsi - m * m / (2.0 * s2v) - log(s2v) / 2.0;  // :123-125
             } else {
                 const double2 k01 = *reinterpret_cast<const double2*>(mycons);
                 const double2 k23 = *reinterpret_cast<const double2*>(mycons + 2);
                 s2v = k23.y;
-                const double dot = fma(st.xtx, bo, U);
+                const double dot = fma(st_xtx, bo, U);
                 m = k01.x * dot;                                      // coreLoop.cpp:42-43
-                a = P.cfac * ((st.lod - m * m * k01.y) + k23.x);      // coreLoop.cpp:45-46
+                a = P.cfac * ((st_lod - m * m * k01.y) + k23.x);      // coreLoop.cpp:45-46
             }
             // exp(-log(1 + exp(a))) = 1 / (1 + exp(a)), evaluated without overflow
             const double e = exp(-fabs(a));
             const double gm = ((a >= 0.0) ? e : 1.0) / (1.0 + e);
             const double bn = m * gm;                            // coreLoop.cpp:48
             const double delta = (act && cvalid) ? (bo - bn) : 0.0;
+            LOCUS_STAMP(3);  // element-wise update
             if (act && writer) {
-                double* o = P.state + (size_t)st.j * d + kl;
+                double* o = P.state + (size_t)st_j * d + kl;
                 o[0] = gm;
                 o[pd] = m;
                 o[2 * pd] = bn;
@@ -365,9 +417,9 @@ sweep_kernel(const SweepParams P)
                 *reinterpret_cast<double2*>(myaccs) = a01;
                 myaccs[2] = a2;
             }
-            // refill the ring slot just consumed with the state of step i + 4
+            // refill the ring slot just consumed with the state of step i + D
             {
-                const size_t off = (size_t)P.steps[i + kUnroll].j * d + kls;
+                const size_t off = (size_t)st_jd * d + kls;
                 bo_ring[u] = P.state[2 * pd + off];
                 if constexpr (LOGIT) {
                     s2_ring[u] = P.s2[off];
@@ -375,6 +427,7 @@ sweep_kernel(const SweepParams P)
                 }
             }
 
+            LOCUS_STAMP(4);  // stores, statistics, state prefetch
             // (6) rank-1 update of the residual columns: R_c += X_j (b_old - b_new)
             double dc[C];
 #pragma unroll
@@ -394,22 +447,33 @@ sweep_kernel(const SweepParams P)
                 }
             }
 
-            // (7) stage column i+2 into the ring slot last read at step i-1
+            LOCUS_STAMP(5);  // broadcast + rank-1 update
+            // (7) stage column i+2 (loaded D steps ago) into the LDS slot last read at step
+            //     i-1, then reuse its registers for the column of step i + 2 + D
             {
                 int wslot = slot + 2;
                 if (wslot >= 3) wslot -= 3;
                 double2* dst = reinterpret_cast<double2*>(xring + wslot * P.npad);
+                const double2* src =
+                    reinterpret_cast<const double2*>(P.Xp + (size_t)st_jx * P.ld);
 #pragma unroll
                 for (int q = 0; q < kMaxPieces; ++q) {
                     const int e = tid + q * nthr;
-                    if (e < npieces) dst[e] = xpre[q];
+                    if (e < npieces) dst[e] = xq[(u + 2) % D][q];
+                    xq[(u + 2) % D][q] = (e < npieces) ? src[e] : make_double2(0.0, 0.0);
                 }
             }
             slot = (slot == 2) ? 0 : slot + 1;
+            LOCUS_STAMP(6);  // X staging (ds_write + next global loads)
             __builtin_amdgcn_sched_barrier(0);  // keep the unrolled steps apart (VGPR budget)
         }
     }
 
+#ifdef LOCUS_STAMPS
+    if (tid == 0 && blockIdx.x < 4096) {
+        for (int k = 0; k < kStampSlots; ++k) g_sweep_stamps[blockIdx.x * kStampSlots + k] = tacc[k];
+    }
+#endif
     // ---- epilogue: residual back to memory, fused statistics -------------------
     // The lane id and the bounds are laundered through empty asm so that the
     // compiler does not keep the C * NPL addresses and masks of the prologue

@@ -56,6 +56,18 @@ def main():
         cfg_used = (_lib.ctypes.c_int32 * 4)()
         _lib.lib().locus_hip_sweep_config(n, d, int(logit), cfg_used)
         upd = nsteps * d / (t * 1e-3)
+        if "diag" in _lib.LIB_PATH:
+            import ctypes
+            c = cfg or tuple(cfg_used)
+            f = getattr(_lib.lib(), f"locus_hip_diag_read_stamps_{c[0]}_{int(logit)}")
+            nwg = min(4096, (d + c[1] * c[3] - 1) // (c[1] * c[3]))
+            buf = (ctypes.c_ulonglong * (8 * nwg))()
+            f(buf, 8 * nwg)
+            a = np.array(buf, dtype=np.float64).reshape(nwg, 8)[:, :7] / nsteps
+            names = ["dot", "reduce", "barrier", "elem", "store/pref", "rank1", "xstage"]
+            print("   cycles/step (median over WGs, s_memtime ticks): " +
+                  " ".join(f"{nm}={v:.0f}" for nm, v in zip(names, np.median(a, axis=0))) +
+                  f" total={np.median(a.sum(axis=1)):.0f}")
         print(f"cfg={cs:12s} auto={list(cfg_used)} ms={t:9.3f} (all {[round(x,2) for x in times]}) "
               f"updates/s={upd:.3e} fp64_TF={(upd*(4*n))/1e12:.2f} algGB/s={upd*(16*n+8*n/d+32)/1e9:.0f}",
               flush=True)

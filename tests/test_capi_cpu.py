@@ -36,7 +36,7 @@ def test_sweep_args_struct_matches_header():
 
 
 @pytest.mark.parametrize("n,d", [(200, 20), (1000, 1000), (1000, 1250), (1000, 10000),
-                                 (2000, 500), (1000, 2000), (64, 1), (4096, 8)])
+                                 (2000, 500), (1000, 2000), (64, 1), (2048, 8)])
 @pytest.mark.parametrize("logit", [0, 1])
 def test_geometry_chooser(n, d, logit):
     from locus_amd import _lib
