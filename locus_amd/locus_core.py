@@ -22,7 +22,23 @@ EPS_SQRT = np.finfo(np.float64).eps ** 0.5  # R/locus_core.R:31
 EPS_MACH = np.finfo(np.float64).eps         # R/elbo.R:46
 
 
-class IdentityHost:
+class HostBase:
+    """What every driver's host side shares: the ONE packed all-reduce per exchange."""
+
+    ent_eps = EPS_MACH  # eps inside the logs of the entropy term (R/elbo.R:46)
+
+    def _all_reduce(self, rs_gam_local, scalars):
+        """ONE all-reduce of [rowSums(gam) (p) | scalars]; returns (rs_gam, scalars) on host."""
+        import torch
+        tail = torch.as_tensor(np.asarray(scalars, dtype=np.float64).reshape(-1),
+                               device=rs_gam_local.device)
+        buf = torch.cat([rs_gam_local.reshape(-1), tail])
+        self.comm.all_reduce_sum_(buf)
+        h = buf.cpu().numpy()
+        return h[: self.p].copy(), h[self.p:].copy()
+
+
+class IdentityHost(HostBase):
     """Replicated / shard-local vector arithmetic of locus_core_ (R/locus_core.R:49-213).
 
     Shard-local (length d_loc): eta, kappa, tau_vb, sig2_beta_vb and the column statistics.
@@ -43,16 +59,6 @@ class IdentityHost:
         self.rs_gam = self.sum_gam = self.sum_tau_m2 = None
         self.stats = None
         self.a_vb = self.b_vb = self.om_vb = None
-
-    # -- exchange ------------------------------------------------------------
-    def _all_reduce(self, rs_gam_local, scalars):
-        """ONE all-reduce of [rowSums(gam) (p) | scalars]; returns (rs_gam, scalars) on host."""
-        import torch
-        tail = torch.tensor(list(scalars), dtype=torch.float64, device=rs_gam_local.device)
-        buf = torch.cat([rs_gam_local.reshape(-1), tail])
-        self.comm.all_reduce_sum_(buf)
-        h = buf.cpu().numpy()
-        return h[: self.p].copy(), h[self.p:].copy()
 
     def set_initial(self, stats, rs_gam_local):
         """R/locus_core.R:36-42: statistics of the initial gam_vb / mu_beta_vb."""
@@ -166,7 +172,7 @@ class IdentityEngine:
                               self._up(prm["scale"]), self._up(prm["hinv"]), self._up(prm["cst"]),
                               self._up(prm["s2k"]), c, self.R, self.state, self.stats)
         rs_gam, ent = dv.gamma_rows(self.state[0], self.p, self.d_loc,
-                                    eps=EPS_MACH if with_elbo else None)
+                                    eps=self.host.ent_eps if with_elbo else None)
         tail = ent.sum().reshape(1) if with_elbo else self.torch.zeros(1, dtype=self.torch.float64,
                                                                       device=self.device)
         h = self.torch.cat([self.stats.reshape(-1), tail]).cpu().numpy()

@@ -75,3 +75,53 @@ def test_identity_annealing(oracle, hip):
                       init["sig2_beta_vb"], init["tau_vb"], **kw)
     np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], rtol=1e-9, atol=1e-12)
     assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+
+
+# ---- structured model (R/locus_struct_core.R) ---------------------------------------------
+def _setup_struct(n=200, p=500, d=20, p0=15, bl=50, seed=5):
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_
+    from locus_amd.simulate import simulate
+    from locus_amd.struct import set_struct
+    sim = simulate(n, p, d, p0, seed=seed)
+    hyper = auto_set_hyper_(sim["Y"], p, p0, struct=True)
+    init = auto_set_init_(sim["Y"], p, p0, user_seed=seed)
+    ls = set_struct(n, p, np.arange(1, p + 1, bl))
+    perms = [np.random.default_rng(100 + i).permutation(p).astype(np.float64) for i in range(64)]
+    return sim, hyper, init, ls, (lambda it: perms[it])
+
+
+@pytest.mark.parametrize("maxit", [1, 4])
+def test_struct_fixed_iterations(oracle, hip, maxit):
+    from oracle import ref_driver
+    from locus_amd.locus_struct_core import locus_struct_core_
+    sim, hyper, init, ls, perm_fn = _setup_struct()
+    ref = ref_driver.locus_struct_core_(sim["Y"], sim["X"], hyper, init["gam_vb"],
+                                        init["mu_beta_vb"], init["sig2_beta_vb"], init["tau_vb"],
+                                        ls["vec_fac_st"], tol=1e-30, maxit=maxit, perm_fn=perm_fn)
+    got = locus_struct_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                             init["sig2_beta_vb"], init["tau_vb"], ls, tol=1e-30, maxit=maxit,
+                             perm_fn=perm_fn, full_output=True)
+    assert got["it"] == ref["it"] == maxit
+    for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    np.testing.assert_allclose(got["theta_vb"], ref["theta_vb"], rtol=1e-9, atol=1e-12)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+    assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+
+
+def test_struct_to_convergence(oracle, hip):
+    from oracle import ref_driver
+    from locus_amd.locus_struct_core import locus_struct_core_
+    sim, hyper, init, ls, perm_fn = _setup_struct(n=150, p=300, d=12, p0=10, bl=30)
+    tr_ref, tr_got = [], []
+    ref = ref_driver.locus_struct_core_(sim["Y"], sim["X"], hyper, init["gam_vb"],
+                                        init["mu_beta_vb"], init["sig2_beta_vb"], init["tau_vb"],
+                                        ls["vec_fac_st"], tol=0.1, maxit=60, perm_fn=perm_fn,
+                                        trace=tr_ref)
+    got = locus_struct_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                             init["sig2_beta_vb"], init["tau_vb"], ls, tol=0.1, maxit=60,
+                             perm_fn=perm_fn, trace=tr_got)
+    assert got["it"] == ref["it"] and got["converged"] == ref["converged"]
+    np.testing.assert_allclose([x[1] for x in tr_got], [x[1] for x in tr_ref], rtol=1e-8)
+    np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
