@@ -207,6 +207,58 @@ int locus_hip_batch_update_dev(double* state, const double* lo, const double* l1
                                double log_sig2_inv, double nm1, int probit, int64_t p,
                                int64_t d, void* stream);
 
+/* ---- binary-response drivers (logit / probit): device side of R/locus_logistic_core.R and
+ * R/locus_probit_core.R around the sweep.  n x d matrices column-major, [p][d] / [q][d]
+ * planes response-contiguous, Z n x q column-major. ---- */
+
+/* D = m2_beta - beta_vb^2 = gam (mu^2 + s2) - (gam mu)^2 on [p][d] planes; s2 from s2jk[p][d]
+ * (logit) or the scalar s2c when s2jk == NULL (probit).  Right-hand factor of the X^2
+ * contractions of update_chi_vb_ (R/update_vb.R:163-167), e_y_logit_ (R/elbo.R:210-218),
+ * e_y_probit_ (R/elbo.R:221-237). */
+int locus_hip_m2_minus_b2_dev(const double* state, const double* s2jk, double s2c, double* D,
+                              int64_t p, int64_t d, void* stream);
+
+/* s2 = 1 / (xwx + sig2_inv): update_sig2_beta_logit_vb_ (R/update_vb.R:107-111) from
+ * xwx = crossprod(X^2, 2 psi_vb). */
+int locus_hip_s2_from_xwx_dev(const double* xwx, double sig2_inv, double* s2, int64_t len,
+                              void* stream);
+
+/* update_chi_vb_ + update_psi_logit_vb_ (R/update_vb.R:163-174) fused with e_y_logit_
+ * (R/elbo.R:210-218): c2 = Q + M^2 + Z^2 s2a + Zmu^2 + 2 M Zmu with Q = X^2 D; chi_new =
+ * sqrt(c2), W2_new = 2 psi(chi_new); ey[k] = column sums of e_y_logit_ evaluated with
+ * chi_old / W2_old (skipped when ey == NULL).  s2a is [q][d]. */
+int locus_hip_logit_chi_psi_dev(const double* Q, const double* M, const double* Zmu,
+                                const double* Y, const double* Z, const double* s2a,
+                                const double* chi_old, const double* W2_old, double* chi_new,
+                                double* W2_new, double* ey, int64_t n, int64_t d, int64_t q,
+                                void* stream);
+
+/* update_sig2_alpha_logit_vb_ (R/update_vb.R:52-56): s2a[i][k] = 1 / (sum_r Z_ri^2 W2_rk +
+ * zeta2_inv[i]); zeta2_inv is a device vector [q]. */
+int locus_hip_logit_sig2_alpha_dev(const double* Z, const double* W2, const double* zeta2_inv,
+                                   double* s2a, int64_t n, int64_t d, int64_t q, void* stream);
+
+/* One covariate i of the alpha loop (R/locus_logistic_core.R:79-85 with W2 = 2 psi_vb and
+ * Yw = Y; R/locus_probit_core.R:76-84 with W2 == NULL and Yw = W): updates alpha_i[d] and
+ * Zmu in place.  Zi = Z[, i] (n), s2a_i = sig2_alpha_vb[i, ] (d). */
+int locus_hip_alpha_step_dev(const double* Yw, const double* W2, const double* M, double* Zmu,
+                             const double* Zi, const double* s2a_i, double* alpha_i, int64_t n,
+                             int64_t d, void* stream);
+
+/* update_W_probit_ (R/update_vb.R:382-386, inv_mills_ratio_matrix_ R/utils.R:178-198) fused
+ * with the column sums of e_y_probit_ (R/elbo.R:221-237); Q = X^2 D, zs = Z^2 sig2_alpha (n).
+ * Q == NULL: W only. */
+int locus_hip_probit_w_dev(const double* Y, const double* M, const double* Zmu, const double* Q,
+                           const double* zs, double* W, double* ey, int64_t n, int64_t d,
+                           void* stream);
+
+/* Per-covariate sums over the local responses: rs_gam, entropy term (as gamma_rows),
+ * gls[j] = sum_k gam log(s2), m2[j] = sum_k gam (mu^2 + s2): the O(p d) parts of
+ * e_beta_gamma_bin_ (R/elbo.R:77-87) and update_nu_bin_vb_ (R/update_vb.R:210). */
+int locus_hip_bin_rows_dev(const double* state, const double* s2jk, double s2c, double* rs_gam,
+                           double* ent, double* gls, double* m2, int64_t p, int64_t d, double eps,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,14 @@ SIGNATURES = {
                                   _int, _dbl, _ptr, _i64, _i64, _ptr]),
     "locus_hip_batch_update_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _dbl, _int,
                                           _i64, _i64, _ptr]),
+    "locus_hip_m2_minus_b2_dev": (_int, [_ptr, _ptr, _dbl, _ptr, _i64, _i64, _ptr]),
+    "locus_hip_s2_from_xwx_dev": (_int, [_ptr, _dbl, _ptr, _i64, _ptr]),
+    "locus_hip_logit_chi_psi_dev": (_int, [_ptr] * 11 + [_i64, _i64, _i64, _ptr]),
+    "locus_hip_logit_sig2_alpha_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr]),
+    "locus_hip_alpha_step_dev": (_int, [_ptr] * 7 + [_i64, _i64, _ptr]),
+    "locus_hip_probit_w_dev": (_int, [_ptr] * 7 + [_i64, _i64, _ptr]),
+    "locus_hip_bin_rows_dev": (_int, [_ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _dbl,
+                                      _ptr]),
 }
 
 _lib = None

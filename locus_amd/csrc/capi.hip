@@ -590,4 +590,74 @@ int locus_hip_batch_update_dev(double* state, const double* lo, const double* l1
                         (hipStream_t)stream);
 }
 
+// ---- binary-response drivers ------------------------------------------------------
+
+int locus_hip_m2_minus_b2_dev(const double* state, const double* s2jk, double s2c, double* D,
+                              int64_t p, int64_t d, void* stream)
+{
+    LOCUS_REQUIRE(state && D && p >= 1 && d >= 1, "m2_minus_b2: bad arguments");
+    return m2_minus_b2(state, s2jk, s2c, D, (size_t)p * d, (hipStream_t)stream);
+}
+
+int locus_hip_s2_from_xwx_dev(const double* xwx, double sig2_inv, double* s2, int64_t len,
+                              void* stream)
+{
+    LOCUS_REQUIRE(xwx && s2 && len >= 1, "s2_from_xwx: bad arguments");
+    return s2_from_xwx(xwx, sig2_inv, s2, (size_t)len, (hipStream_t)stream);
+}
+
+int locus_hip_logit_chi_psi_dev(const double* Q, const double* M, const double* Zmu,
+                                const double* Y, const double* Z, const double* s2a,
+                                const double* chi_old, const double* W2_old, double* chi_new,
+                                double* W2_new, double* ey, int64_t n, int64_t d, int64_t q,
+                                void* stream)
+{
+    LOCUS_REQUIRE(Q && M && Zmu && Z && s2a && chi_new && W2_new && n >= 1 && d >= 1 && q >= 1 &&
+                      n < (1ll << 31) && d < (1ll << 31) && q < (1ll << 31),
+                  "logit_chi_psi: bad arguments");
+    if (ey) LOCUS_REQUIRE(Y && chi_old && W2_old, "logit_chi_psi: ELBO part needs Y, chi_old, W2_old");
+    return logit_chi_psi(Q, M, Zmu, Y, Z, s2a, chi_old, W2_old, chi_new, W2_new, ey, (int)n, (int)d,
+                         (int)q, (hipStream_t)stream);
+}
+
+int locus_hip_logit_sig2_alpha_dev(const double* Z, const double* W2, const double* zeta2_inv,
+                                   double* s2a, int64_t n, int64_t d, int64_t q, void* stream)
+{
+    LOCUS_REQUIRE(Z && W2 && zeta2_inv && s2a && n >= 1 && d >= 1 && q >= 1 && n < (1ll << 31) &&
+                      d < (1ll << 31) && q < (1ll << 31),
+                  "logit_sig2_alpha: bad arguments");
+    return logit_sig2_alpha(Z, W2, zeta2_inv, s2a, (int)n, (int)d, (int)q, (hipStream_t)stream);
+}
+
+int locus_hip_alpha_step_dev(const double* Yw, const double* W2, const double* M, double* Zmu,
+                             const double* Zi, const double* s2a_i, double* alpha_i, int64_t n,
+                             int64_t d, void* stream)
+{
+    LOCUS_REQUIRE(Yw && M && Zmu && Zi && s2a_i && alpha_i && n >= 1 && d >= 1 && n < (1ll << 31) &&
+                      d < (1ll << 31),
+                  "alpha_step: bad arguments");
+    return alpha_step(Yw, W2, M, Zmu, Zi, s2a_i, alpha_i, (int)n, (int)d, (hipStream_t)stream);
+}
+
+int locus_hip_probit_w_dev(const double* Y, const double* M, const double* Zmu, const double* Q,
+                           const double* zs, double* W, double* ey, int64_t n, int64_t d,
+                           void* stream)
+{
+    LOCUS_REQUIRE(Y && M && Zmu && W && n >= 1 && d >= 1 && n < (1ll << 31) && d < (1ll << 31),
+                  "probit_w: bad arguments");
+    if (Q) LOCUS_REQUIRE(zs && ey, "probit_w: ELBO part needs zs and ey");
+    return probit_w(Y, M, Zmu, Q, zs, W, ey, (int)n, (int)d, (hipStream_t)stream);
+}
+
+int locus_hip_bin_rows_dev(const double* state, const double* s2jk, double s2c, double* rs_gam,
+                           double* ent, double* gls, double* m2, int64_t p, int64_t d, double eps,
+                           void* stream)
+{
+    LOCUS_REQUIRE(state && rs_gam && ent && gls && m2 && p >= 1 && d >= 1 && p < (1ll << 31) &&
+                      d < (1ll << 31),
+                  "bin_rows: bad arguments");
+    return bin_rows(state, s2jk, s2c, rs_gam, ent, gls, m2, (int)p, (int)d, eps,
+                    (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -20,6 +20,22 @@ int batch_update(double* state, const double* lo, const double* l1, const double
                  const double* hinv, const double* cstk, double log_sig2_inv, double nm1,
                  int probit, int p, int d, hipStream_t st);
 
+// binary-response drivers (link.hip)
+int m2_minus_b2(const double* state, const double* s2jk, double s2c, double* D, size_t pd,
+                hipStream_t st);
+int s2_from_xwx(const double* xwx, double sig2_inv, double* s2, size_t len, hipStream_t st);
+int logit_chi_psi(const double* Q, const double* M, const double* Zmu, const double* Y,
+                  const double* Z, const double* s2a, const double* chi_old, const double* W2_old,
+                  double* chi_new, double* W2_new, double* ey, int n, int d, int q, hipStream_t st);
+int logit_sig2_alpha(const double* Z, const double* W2, const double* zeta2_inv, double* s2a,
+                     int n, int d, int q, hipStream_t st);
+int alpha_step(const double* Yw, const double* W2, const double* M, double* Zmu, const double* Zi,
+               const double* s2a_i, double* alpha_i, int n, int d, hipStream_t st);
+int probit_w(const double* Y, const double* M, const double* Zmu, const double* Q, const double* zs,
+             double* W, double* ey, int n, int d, hipStream_t st);
+int bin_rows(const double* state, const double* s2jk, double s2c, double* rs_gam, double* ent,
+             double* gls, double* m2, int p, int d, double eps, hipStream_t st);
+
 // C (m x n) = alpha * op(A) * op(B) + beta * C with arbitrary element strides;
 // fp64 MFMA (v_mfma_f64_16x16x4_f64).  sqA squares A's elements on load (X^2 products
 // of update_vb.R:107-111,163-167 without materialising X^2).

@@ -156,3 +156,46 @@ def batch_update(state, lo, l1, fac, hinv, cstk, log_sig2_inv, nm1, probit, p, d
     _lib.check(_lib.lib().locus_hip_batch_update_dev(_p(state), _p(lo), _p(l1), _p(fac), _p(hinv),
                                                      _p(cstk), float(log_sig2_inv), float(nm1),
                                                      int(probit), p, d, _stream()))
+
+
+# ---- binary-response drivers (link.hip) ---------------------------------------------------
+def m2_minus_b2(state, p, d, D, s2jk=None, s2c=0.0):
+    _lib.check(_lib.lib().locus_hip_m2_minus_b2_dev(_p(state), _p(s2jk), float(s2c), _p(D), p, d,
+                                                    _stream()))
+    return D
+
+
+def s2_from_xwx(xwx, sig2_inv, s2):
+    _lib.check(_lib.lib().locus_hip_s2_from_xwx_dev(_p(xwx), float(sig2_inv), _p(s2), xwx.numel(),
+                                                    _stream()))
+    return s2
+
+
+def logit_chi_psi(Q, M, Zmu, Y, Z, s2a, chi_old, W2_old, chi_new, W2_new, ey, n, d, q):
+    _lib.check(_lib.lib().locus_hip_logit_chi_psi_dev(_p(Q), _p(M), _p(Zmu), _p(Y), _p(Z), _p(s2a),
+                                                      _p(chi_old), _p(W2_old), _p(chi_new),
+                                                      _p(W2_new), _p(ey), n, d, q, _stream()))
+
+
+def logit_sig2_alpha(Z, W2, zeta2_inv, s2a, n, d, q):
+    _lib.check(_lib.lib().locus_hip_logit_sig2_alpha_dev(_p(Z), _p(W2), _p(zeta2_inv), _p(s2a), n, d,
+                                                         q, _stream()))
+
+
+def alpha_step(Yw, W2, M, Zmu, Zi, s2a_i, alpha_i, n, d):
+    _lib.check(_lib.lib().locus_hip_alpha_step_dev(_p(Yw), _p(W2), _p(M), _p(Zmu), _p(Zi),
+                                                   _p(s2a_i), _p(alpha_i), n, d, _stream()))
+
+
+def probit_w(Y, M, Zmu, Q, zs, W, ey, n, d):
+    _lib.check(_lib.lib().locus_hip_probit_w_dev(_p(Y), _p(M), _p(Zmu), _p(Q), _p(zs), _p(W), _p(ey),
+                                                 n, d, _stream()))
+
+
+def bin_rows(state, p, d, eps, s2jk=None, s2c=1.0):
+    """rs_gam, ent, gls, m2 as one [4][p] tensor."""
+    out = torch.empty((4, p), dtype=F64, device=state.device)
+    _lib.check(_lib.lib().locus_hip_bin_rows_dev(_p(state), _p(s2jk), float(s2c), _p(out[0]),
+                                                 _p(out[1]), _p(out[2]), _p(out[3]), p, d,
+                                                 float(eps), _stream()))
+    return out

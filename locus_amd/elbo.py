@@ -52,3 +52,16 @@ def e_tau_(eta, eta_vb, kappa, kappa_vb, log_tau_vb, tau_vb):  # :138-143
 def e_zeta2_inv_(log_zeta2_inv_vb, phi, phi_vb, xi, xi_vb, zeta2_inv_vb):  # :244-249
     return np.sum((phi - phi_vb) * log_zeta2_inv_vb - (xi - xi_vb) * zeta2_inv_vb
                   + phi * np.log(xi) - phi_vb * np.log(xi_vb) - gammaln(phi) + gammaln(phi_vb))
+
+
+def e_alpha_logit_(rs_m2_alpha, sum_log_sig2_alpha, q, d, log_zeta2_inv_vb, zeta2_inv_vb):
+    """R/elbo.R:22-27 on reduced statistics: rs_m2_alpha = rowSums(m2_alpha) (q),
+    sum_log_sig2_alpha = sum(log(sig2_alpha_vb)) over the q x d matrix."""
+    return 0.5 * (-np.sum(rs_m2_alpha * zeta2_inv_vb) + d * np.sum(log_zeta2_inv_vb)
+                  + sum_log_sig2_alpha + q * d)
+
+
+def e_alpha_probit_(rs_m2_alpha, sig2_alpha_vb, q, d, log_zeta2_inv_vb, zeta2_inv_vb):
+    """R/elbo.R:30-35 (sig2_alpha_vb is a length-q vector swept over responses)."""
+    return 0.5 * (-np.sum(rs_m2_alpha * zeta2_inv_vb)
+                  + d * np.sum(log_zeta2_inv_vb + np.log(sig2_alpha_vb)) + q * d)

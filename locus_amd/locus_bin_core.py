@@ -1,0 +1,346 @@
+"""Binary-response CAVI drivers with device-resident state:
+  locus_logit_core_   mirrors R/locus_logistic_core.R:8-265 (Jaakkola-Jordan bound, chi / psi)
+  locus_probit_core_  mirrors R/locus_probit_core.R:8-250   (latent W, inverse Mills ratio)
+
+Resident per GPU (responses sharded, X and Z replicated): packed X, Y, mat_x_m1, mat_z_mu,
+the residual, Q = X^2 (m2_beta - beta_vb^2), the [p][d] state planes and, for logit, the
+[p][d] sig2_beta_vb / xwx planes and double-buffered chi_vb / 2 psi_vb.
+
+X^2 contractions per iteration (fp64 matrix cores): the reference does five for logit
+(update_chi_vb_ x2, update_sig2_beta_logit_vb_, e_y_logit_ x2); here two suffice:
+  Q   = X^2 (m2_beta - beta_vb^2)   serves e_y_logit_ of iteration t AND chi_vb of iteration t+1
+        (both are evaluated on the same end-of-iteration state, R/elbo.R:213-216 vs
+        R/update_vb.R:165-166 with Z^2 m2_alpha - Z^2 alpha^2 = Z^2 sig2_alpha);
+  xwx = crossprod(X^2, 2 psi_vb)    serves sig2_beta_vb AND the sweep's folded dot product.
+Probit needs Q only (e_y_probit_, R/elbo.R:228).
+
+Exchange: ONE all-reduce per iteration of [rowSums(gam_vb) (p) | sum(m2_beta) |
+rowSums(m2_alpha) (q) | shard-local ELBO sums].
+"""
+import numpy as np
+from scipy.special import digamma
+
+from . import elbo as E
+from . import update_vb as U
+from .comm import Comm
+from .locus_core import EPS_MACH, HostBase, _gather
+
+
+class BinHost(HostBase):
+    """Replicated vector arithmetic shared by the logit and probit drivers."""
+
+    def __init__(self, n, p, d_total, q, hyper, comm=None):
+        self.n, self.p, self.d, self.q = int(n), int(p), int(d_total), int(q)
+        self.comm = comm or Comm()
+        self.a = np.broadcast_to(np.asarray(hyper["a"], dtype=np.float64), (p,)).copy()
+        self.b = np.broadcast_to(np.asarray(hyper["b"], dtype=np.float64), (p,)).copy()
+        self.lam, self.nu = float(hyper["lambda"]), float(hyper["nu"])
+        self.phi = np.atleast_1d(np.asarray(hyper["phi"], dtype=np.float64))
+        self.xi = np.atleast_1d(np.asarray(hyper["xi"], dtype=np.float64))
+        self.phi_vb = U.update_phi_z_vb_(self.phi, self.d)          # logistic_core.R:30
+        self.digam_sum = digamma(self.a + self.b + self.d)          # :34
+        self.rs_gam = self.sum_gam = self.sum_m2 = self.rs_m2_alpha = None
+        self.sig2_inv_vb = self.zeta2_inv_vb = None
+        self.a_vb = self.b_vb = self.om_vb = None
+
+    def exchange(self, rs_gam_local, sum_m2_loc, rs_m2_alpha_loc, extra):
+        tail = np.concatenate([[sum_m2_loc], rs_m2_alpha_loc, np.atleast_1d(extra)])
+        self.rs_gam, sc = self._all_reduce(rs_gam_local, tail)
+        self.sum_gam = float(self.rs_gam.sum())
+        self.sum_m2 = float(sc[0])
+        self.rs_m2_alpha = sc[1:1 + self.q].copy()
+        return sc[1 + self.q:]
+
+    def begin_iteration(self):
+        """logistic_core.R:55-77 / probit_core.R:51-74 (the parts common to both links)."""
+        xi_vb = U.update_xi_bin_vb_(self.xi, self.rs_m2_alpha)
+        self.zeta2_inv_vb = self.phi_vb / xi_vb
+        lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam)
+        nu_vb = U.update_nu_bin_vb_(self.nu, self.sum_m2)
+        self.sig2_inv_vb = lambda_vb / nu_vb
+        return dict(log_sig2_inv_vb=float(U.update_log_sig2_inv_vb_(lambda_vb, nu_vb)),
+                    lo=U.update_log_om_vb(self.a, self.digam_sum, self.rs_gam),
+                    l1=U.update_log_1_min_om_vb(self.b, self.d, self.digam_sum, self.rs_gam))
+
+    def finish_elbo(self, loc_sum, e_alpha_fn):
+        """Replicated part of elbo_logit_ / elbo_probit_ (logistic_core.R:276-301,
+        probit_core.R:262-286); loc_sum = all-reduced shard-local sums."""
+        d = self.d
+        self.a_vb = U.update_a_vb(self.a, self.rs_gam)
+        self.b_vb = U.update_b_vb(self.b, d, self.rs_gam)
+        self.om_vb = self.a_vb / (self.a_vb + self.b_vb)
+        lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam)
+        nu_vb = U.update_nu_bin_vb_(self.nu, self.sum_m2)
+        xi_vb = U.update_xi_bin_vb_(self.xi, self.rs_m2_alpha)
+        log_sig2_inv_vb = digamma(lambda_vb) - np.log(nu_vb)
+        log_zeta2_inv_vb = digamma(self.phi_vb) - np.log(xi_vb)
+        log_om_vb = digamma(self.a_vb) - digamma(self.a_vb + self.b_vb)
+        log_1_min_om_vb = digamma(self.b_vb) - digamma(self.a_vb + self.b_vb)
+        si = self.sig2_inv_vb
+        glob = (log_sig2_inv_vb * self.sum_gam / 2 - self.sum_m2 * si / 2
+                + np.sum(self.rs_gam * log_om_vb)
+                + np.sum((d - self.rs_gam) * log_1_min_om_vb))          # R/elbo.R:81-83
+        return float(loc_sum + glob
+                     + E.e_sig2_inv_(self.lam, lambda_vb, log_sig2_inv_vb, self.nu, nu_vb, si)
+                     + E.e_omega_(self.a, self.a_vb, self.b, self.b_vb, log_om_vb,
+                                  log_1_min_om_vb)
+                     + e_alpha_fn(log_zeta2_inv_vb)
+                     + E.e_zeta2_inv_(log_zeta2_inv_vb, self.phi, self.phi_vb, self.xi, xi_vb,
+                                      self.zeta2_inv_vb))
+
+
+class BinEngine:
+    """One GPU's shard of a binary-response model (link = 'logit' | 'probit')."""
+
+    def __init__(self, link, px, Y_dev, Z, state, alpha_vb, sig2_alpha_vb, sig2_beta_vb, host,
+                 device):
+        import torch
+        from . import device as dv
+        assert link in ("logit", "probit")
+        self.link, self.torch, self.dv = link, torch, dv
+        self.px, self.Y, self.state, self.host, self.device = px, Y_dev, state, host, device
+        self.n, self.d_loc = Y_dev.shape
+        self.p, self.q = px.p, Z.shape[1]
+        n, p, d, q = self.n, self.p, self.d_loc, self.q
+        assert tuple(state.shape) == (3, p, d)
+        self.Z_host = np.asfortranarray(Z, dtype=np.float64)
+        self.Z = dv.to_device_colmajor(self.Z_host, device)            # n x q, column j contiguous
+        self.Zt = self.Z.t().contiguous()                               # [q][n]
+        self.alpha = self._up(np.ascontiguousarray(alpha_vb, dtype=np.float64).reshape(q, d))
+        f64 = torch.float64
+        cm = lambda: torch.empty((d, n), dtype=f64, device=device).t()  # noqa: E731
+        self.M, self.Zmu, self.R, self.Q = cm(), cm(), cm(), cm()
+        self.D = torch.empty((p, d), dtype=f64, device=device)
+        self.sweeper = dv.Sweeper(px, d, device)
+        if link == "logit":
+            self.s2 = torch.from_numpy(np.ascontiguousarray(sig2_beta_vb, dtype=np.float64)).to(device)
+            assert tuple(self.s2.shape) == (p, d)
+            self.xwx = torch.empty((p, d), dtype=f64, device=device)
+            self.s2a = self._up(np.ascontiguousarray(sig2_alpha_vb, dtype=np.float64).reshape(q, d))
+            self.chi = [cm(), cm()]
+            self.W2 = [cm(), cm()]
+            self.cur = 0
+        else:
+            self.s2c = float(sig2_beta_vb)
+            self.s2a_vec = np.atleast_1d(np.asarray(sig2_alpha_vb, dtype=np.float64)).copy()
+            self.W = cm()
+        self.ey = torch.empty((d,), dtype=f64, device=device)
+
+    def _up(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    # -- shared pieces -----------------------------------------------------------------
+    def _rows(self):
+        dv = self.dv
+        if self.link == "logit":
+            return dv.bin_rows(self.state, self.p, self.d_loc, EPS_MACH, s2jk=self.s2)
+        return dv.bin_rows(self.state, self.p, self.d_loc, EPS_MACH, s2c=self.s2c)
+
+    def _contract_Q(self):
+        """Q = X^2 (m2_beta - beta_vb^2): n x d on the matrix cores."""
+        dv, n, p, d = self.dv, self.n, self.p, self.d_loc
+        if self.link == "logit":
+            dv.m2_minus_b2(self.state, p, d, self.D, s2jk=self.s2)
+        else:
+            dv.m2_minus_b2(self.state, p, d, self.D, s2c=self.s2c)
+        dv.gemm(n, d, p, self.px.Xp, 1, self.px.ld, self.D, d, 1, self.Q, 1, n, sqA=True)
+
+    def _m2_alpha_rows(self):
+        """rowSums(m2_alpha) over the local responses (update_m2_alpha_, R/update_vb.R:18-29)
+        and sum(log(sig2_alpha_vb)) for e_alpha_logit_."""
+        a = self.alpha.cpu().numpy()
+        if self.link == "logit":
+            s2a = self.s2a.cpu().numpy()
+            return (s2a + a ** 2).sum(axis=1), float(np.log(s2a).sum())
+        return (a ** 2 + self.s2a_vec[:, None]).sum(axis=1), 0.0
+
+    def initialise(self):
+        """logistic_core.R:23-34 / probit_core.R:23-36."""
+        t, dv = self.torch, self.dv
+        n, p, d, q = self.n, self.p, self.d_loc, self.q
+        if self.link == "logit":
+            dv.state_cols(self.state, p, d, s2jk=self.s2)    # writes beta = gam * mu
+        else:
+            dv.state_cols(self.state, p, d, s2k=t.full((d,), self.s2c, dtype=t.float64,
+                                                       device=self.device))
+        dv.gemm(n, d, p, self.px.Xp, 1, self.px.ld, self.state[2], d, 1, self.M, 1, n)
+        self.Zmu.copy_(self._up((self.Z_host @ self.alpha.cpu().numpy()).T).t())
+        rows = self._rows()
+        rs_m2a, _ = self._m2_alpha_rows()
+        self.host.exchange(rows[0], float(rows[3].sum().item()), rs_m2a, [])
+        if self.link == "logit":
+            self._contract_Q()
+            nxt = 1 - self.cur
+            dv.logit_chi_psi(self.Q, self.M, self.Zmu, None, self.Z, self.s2a, None, None,
+                             self.chi[nxt], self.W2[nxt], None, n, d, q)
+        else:
+            dv.probit_w(self.Y, self.M, self.Zmu, None, None, self.W, None, n, d)
+
+    def iterate(self, shuffled_ind, alpha_order=None):
+        """One pass of the loop body (logistic_core.R:40-225 / probit_core.R:42-210)."""
+        t, dv, host = self.torch, self.dv, self.host
+        n, p, d, q = self.n, self.p, self.d_loc, self.q
+        prm = host.begin_iteration()
+        ind = shuffled_ind if t.is_tensor(shuffled_ind) else self._up(shuffled_ind)
+        lo, l1 = self._up(prm["lo"]), self._up(prm["l1"])
+        order = range(q) if alpha_order is None else alpha_order
+        if self.link == "logit":
+            self.cur = 1 - self.cur                                   # chi_vb, psi_vb of this iteration
+            W2 = self.W2[self.cur]
+            dv.logit_sig2_alpha(self.Z, W2, self._up(host.zeta2_inv_vb), self.s2a, n, d, q)
+            # xwx = crossprod(X^2, 2 psi) -> sig2_beta_vb = 1 / (xwx + sig2_inv_vb)
+            dv.gemm(p, d, n, self.px.Xp, self.px.ld, 1, W2, 1, n, self.xwx, d, 1, sqA=True)
+            dv.s2_from_xwx(self.xwx, host.sig2_inv_vb, self.s2)
+            for i in order:
+                dv.alpha_step(self.Y, W2, self.M, self.Zmu, self.Zt[i], self.s2a[i], self.alpha[i],
+                              n, d)
+            dv.residual(self.Y, self.M, self.Zmu, W2, out=self.R, to_residual=True)
+            self.sweeper.logit(ind, lo, l1, self.s2, self.xwx, W2, prm["log_sig2_inv_vb"] / 2,
+                               self.R, self.state)
+            dv.residual(self.Y, self.R, self.Zmu, W2, out=self.M, to_residual=False)
+        else:
+            self.s2a_vec = U.update_sig2_alpha_vb_(n, host.zeta2_inv_vb, intercept=True)  # :63
+            self.s2c = float(U.update_sig2_beta_vb_(n, host.sig2_inv_vb))                 # :64
+            for i in order:
+                s2a_i = t.full((d,), float(self.s2a_vec[i]), dtype=t.float64, device=self.device)
+                dv.alpha_step(self.W, None, self.M, self.Zmu, self.Zt[i], s2a_i, self.alpha[i], n, d)
+            dv.residual(self.W, self.M, self.Zmu, out=self.R)
+            full = lambda v: t.full((d,), float(v), dtype=t.float64, device=self.device)  # noqa: E731
+            s2 = self.s2c                                             # src/coreLoop.cpp:152,160
+            self.sweeper.identity(ind, lo, l1, full(s2), full(1.0 / (2.0 * s2)),
+                                  full(-(prm["log_sig2_inv_vb"] + np.log(s2)) / 2), full(s2), 1.0,
+                                  self.R, self.state)
+            dv.residual(self.W, self.R, self.Zmu, out=self.M)
+        rows = self._rows()
+        self._contract_Q()
+        if self.link == "logit":
+            nxt = 1 - self.cur
+            dv.logit_chi_psi(self.Q, self.M, self.Zmu, self.Y, self.Z, self.s2a, self.chi[self.cur],
+                             self.W2[self.cur], self.chi[nxt], self.W2[nxt], self.ey, n, d, q)
+        else:
+            zs = self._up((self.Z_host ** 2) @ self.s2a_vec)
+            dv.probit_w(self.Y, self.M, self.Zmu, self.Q, zs, self.W, self.ey, n, d)
+        sums = t.cat([rows[1:].sum(dim=1), self.ey.sum().reshape(1)]).cpu().numpy()
+        self.sweeper.status()
+        ent, gls, sum_m2, ey = (float(v) for v in sums)
+        rs_m2a, sum_log_s2a = self._m2_alpha_rows()
+        rs_gam_loc_sum = float(rows[0].sum().item())
+        # shard-local sums of the ELBO: e_y_*, and of e_beta_gamma_bin_ the terms
+        # gam (log sig2_beta + 1) / 2 and the entropy (R/elbo.R:84-85)
+        loc = ey + (gls + rs_gam_loc_sum) / 2 - ent
+        tot = host.exchange(rows[0], sum_m2, rs_m2a, [loc, sum_log_s2a])
+        if self.link == "logit":
+            fn = lambda lz: E.e_alpha_logit_(host.rs_m2_alpha, float(tot[1]), q, host.d, lz,  # noqa: E731
+                                             host.zeta2_inv_vb)
+        else:
+            fn = lambda lz: E.e_alpha_probit_(host.rs_m2_alpha, self.s2a_vec, q, host.d, lz,  # noqa: E731
+                                              host.zeta2_inv_vb)
+        return host.finish_elbo(float(tot[0]), fn)
+
+    def download(self):
+        out = {}
+        for name, qq in (("gam_vb", 0), ("mu_beta_vb", 1), ("beta_vb", 2)):
+            out[name] = self.state[qq].cpu().numpy().copy(order="F")
+        out["mat_x_m1"] = self.M.cpu().numpy().copy(order="F")
+        out["mat_z_mu"] = self.Zmu.cpu().numpy().copy(order="F")
+        out["alpha_vb"] = self.alpha.cpu().numpy().copy()
+        if self.link == "logit":
+            out["sig2_beta_vb"] = self.s2.cpu().numpy().copy(order="F")
+            out["psi_vb"] = (self.W2[self.cur] / 2).cpu().numpy().copy(order="F")
+            out["chi_vb"] = self.chi[self.cur].cpu().numpy().copy(order="F")
+        else:
+            out["sig2_beta_vb"] = self.s2c
+        return out
+
+
+def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb, sig2_beta_vb,
+         tol, maxit, verbose, batch, full_output, debug, perm_fn, alpha_perm_fn, comm, device,
+         trace):
+    import torch
+    from . import device as dv
+    dv.require_gpu()
+    if batch != "y":
+        raise NotImplementedError("only the 'y' scheme is device-resident")
+    comm = comm or Comm()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    Y = np.asarray(Y, dtype=np.float64)
+    X = np.asarray(X, dtype=np.float64)
+    Z = np.asarray(Z, dtype=np.float64)
+    n, d = Y.shape
+    p, q = X.shape[1], Z.shape[1]
+    k_lo, k_hi = comm.shard(d)
+    if perm_fn is None:
+        rng = np.random.default_rng(0)
+        perm_fn = lambda it: rng.permutation(p).astype(np.float64)  # noqa: E731
+    host = BinHost(n, p, d, q, list_hyper, comm)
+    px = dv.PackedX(dv.to_device_colmajor(X, device))
+    Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
+    state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)
+    state[0] = torch.from_numpy(np.ascontiguousarray(np.asarray(gam_vb)[:, k_lo:k_hi])).to(device)
+    state[1] = torch.from_numpy(np.ascontiguousarray(np.asarray(mu_beta_vb)[:, k_lo:k_hi])).to(device)
+    alpha_loc = np.asarray(alpha_vb, dtype=np.float64).reshape(q, d)[:, k_lo:k_hi]
+    if link == "logit":
+        s2a_loc = np.asarray(sig2_alpha_vb, dtype=np.float64).reshape(q, d)[:, k_lo:k_hi]
+        s2b_loc = np.asarray(sig2_beta_vb, dtype=np.float64)[:, k_lo:k_hi]
+    else:
+        s2a_loc, s2b_loc = sig2_alpha_vb, float(sig2_beta_vb)
+    eng = BinEngine(link, px, Y_dev, Z, state, alpha_loc, s2a_loc, s2b_loc, host, device)
+    eng.initialise()
+
+    converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
+    while (not converged) and it < maxit:
+        lb_old = lb_new
+        it += 1
+        if verbose and (it == 1 or it % 5 == 0):
+            print(f"Iteration {it}... ")
+        order = None if alpha_perm_fn is None else alpha_perm_fn(it)
+        lb_new = eng.iterate(np.ascontiguousarray(perm_fn(it), dtype=np.float64), order)
+        if trace is not None:
+            trace.append((it, lb_new))
+        if verbose and (it == 1 or it % 5 == 0):
+            print(f"ELBO = {lb_new}\n")
+        if debug and lb_new < lb_old:
+            raise RuntimeError("ELBO not increasing monotonically. Exit. ")
+        converged = abs(lb_new - lb_old) < tol
+    if verbose and not converged:
+        print("Maximal number of iterations reached before convergence. Exit.")
+
+    loc = eng.download()
+    g = lambda key: _gather(comm, loc[key], d)  # noqa: E731
+    out = dict(beta_vb=g("beta_vb"), gam_vb=g("gam_vb"), om_vb=host.om_vb,
+               alpha_vb=g("alpha_vb"), converged=converged, it=it, lb_opt=lb_new,
+               diff_lb=abs(lb_new - lb_old))
+    if full_output:
+        out.update(mu_beta_vb=g("mu_beta_vb"), mat_x_m1=g("mat_x_m1"), mat_z_mu=g("mat_z_mu"),
+                   sig2_inv_vb=host.sig2_inv_vb, zeta2_inv_vb=host.zeta2_inv_vb,
+                   a_vb=host.a_vb, b_vb=host.b_vb, sum_gam=host.sum_gam)
+        if link == "logit":
+            out.update(sig2_beta_vb=g("sig2_beta_vb"), psi_vb=g("psi_vb"), chi_vb=g("chi_vb"))
+        else:
+            out.update(sig2_beta_vb=loc["sig2_beta_vb"])
+    return out
+
+
+def locus_logit_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
+                      sig2_beta_vb, tol, maxit, verbose=False, batch="y", full_output=False,
+                      debug=False, perm_fn=None, alpha_perm_fn=None, comm=None, device=None,
+                      trace=None):
+    """R/locus_logistic_core.R:8-265 on the GPU.  Y has 1/2 subtracted, X standardised, Z holds
+    the intercept / fixed covariates (n x q); alpha_vb, sig2_alpha_vb are q x d and
+    sig2_beta_vb is p x d.  The reference's `chi_vb` argument is overwritten before its
+    first use (:49) and is therefore not taken.  `alpha_perm_fn(it)` gives the order of the
+    alpha loop (R: sample(1:q), :79; 0-based here), `perm_fn(it)` the SNP sweep order."""
+    return _run("logit", Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
+                sig2_beta_vb, tol, maxit, verbose, batch, full_output, debug, perm_fn,
+                alpha_perm_fn, comm, device, trace)
+
+
+def locus_probit_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
+                       sig2_beta_vb, tol, maxit, verbose=False, batch="y", full_output=False,
+                       debug=False, perm_fn=None, alpha_perm_fn=None, comm=None, device=None,
+                       trace=None):
+    """R/locus_probit_core.R:8-250 on the GPU.  Y is 0/1, Z[:, 0] is the intercept (:13);
+    sig2_alpha_vb is a length-q vector and sig2_beta_vb a scalar."""
+    return _run("probit", Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
+                sig2_beta_vb, tol, maxit, verbose, batch, full_output, debug, perm_fn,
+                alpha_perm_fn, comm, device, trace)

@@ -125,3 +125,69 @@ def test_struct_to_convergence(oracle, hip):
     np.testing.assert_allclose([x[1] for x in tr_got], [x[1] for x in tr_ref], rtol=1e-8)
     np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], rtol=1e-9, atol=1e-12)
     assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+
+
+# ---- binary responses (R/locus_logistic_core.R, R/locus_probit_core.R) ----------------------
+def _setup_bin(link, n=200, p=300, d=12, p0=10, q=1, seed=9):
+    from locus_amd.prepare import add_intercept_, auto_set_hyper_, auto_set_init_
+    from locus_amd.simulate import simulate
+    sim = simulate(n, p, d, p0, seed=seed, link=link)
+    hyper = auto_set_hyper_(sim["Y"], p, p0, q=1, link=link)
+    init = auto_set_init_(sim["Y"], p, p0, q=1, user_seed=seed, link=link)
+    Z = add_intercept_(n, d, hyper, init, link)
+    if q > 1:  # fixed covariates next to the intercept (R/locus.R:401-425)
+        rng = np.random.default_rng(seed + 1)
+        Zc = rng.normal(size=(n, q - 1))
+        Zc = (Zc - Zc.mean(axis=0)) / Zc.std(axis=0, ddof=1)
+        Z = np.asfortranarray(np.hstack([Z, Zc]))
+        hyper["phi"] = np.concatenate([hyper["phi"], np.ones(q - 1)])
+        hyper["xi"] = np.concatenate([hyper["xi"], np.ones(q - 1)])
+        init["alpha_vb"] = rng.normal(scale=0.1, size=(q, d))
+        init["sig2_alpha_vb"] = (np.full(q, 0.5) if link == "probit"
+                                 else rng.gamma(2.0, 0.2, size=(q, d)))
+    perms = [np.random.default_rng(200 + i).permutation(p).astype(np.float64) for i in range(64)]
+    aperms = [np.random.default_rng(300 + i).permutation(q) for i in range(64)]
+    return sim, hyper, init, Z, (lambda it: perms[it]), (lambda it: aperms[it])
+
+
+@pytest.mark.parametrize("link", ["logit", "probit"])
+@pytest.mark.parametrize("q,maxit", [(1, 1), (1, 4), (3, 3)])
+def test_binary_fixed_iterations(oracle, hip, link, q, maxit):
+    from oracle import ref_driver
+    from locus_amd import locus_bin_core
+    sim, hyper, init, Z, perm_fn, aperm_fn = _setup_bin(link, q=q)
+    ref_fn = getattr(ref_driver, f"locus_{link}_core_")
+    got_fn = getattr(locus_bin_core, f"locus_{link}_core_")
+    args = (sim["Y"], sim["X"], Z, hyper, init["gam_vb"], init["alpha_vb"], init["mu_beta_vb"],
+            init["sig2_alpha_vb"], init["sig2_beta_vb"])
+    ref = ref_fn(*args, tol=1e-30, maxit=maxit, perm_fn=perm_fn, alpha_perm_fn=aperm_fn)
+    got = got_fn(*args, tol=1e-30, maxit=maxit, perm_fn=perm_fn, alpha_perm_fn=aperm_fn,
+                 full_output=True)
+    assert got["it"] == ref["it"] == maxit
+    for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1", "mat_z_mu", "alpha_vb"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    np.testing.assert_allclose(got["sig2_beta_vb"], ref["sig2_beta_vb"], rtol=1e-10)
+    if link == "logit":
+        np.testing.assert_allclose(got["psi_vb"], ref["psi_vb"], rtol=1e-9)
+    np.testing.assert_allclose(got["om_vb"], ref["om_vb"], rtol=1e-9)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+    assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+
+
+@pytest.mark.parametrize("link", ["logit", "probit"])
+def test_binary_to_convergence(oracle, hip, link):
+    from oracle import ref_driver
+    from locus_amd import locus_bin_core
+    sim, hyper, init, Z, perm_fn, aperm_fn = _setup_bin(link, n=150, p=200, d=8, p0=8)
+    args = (sim["Y"], sim["X"], Z, hyper, init["gam_vb"], init["alpha_vb"], init["mu_beta_vb"],
+            init["sig2_alpha_vb"], init["sig2_beta_vb"])
+    tr_ref, tr_got = [], []
+    ref = getattr(ref_driver, f"locus_{link}_core_")(*args, tol=0.1, maxit=60, perm_fn=perm_fn,
+                                                     trace=tr_ref)
+    got = getattr(locus_bin_core, f"locus_{link}_core_")(*args, tol=0.1, maxit=60,
+                                                         perm_fn=perm_fn, trace=tr_got)
+    assert got["it"] == ref["it"] and got["converged"] == ref["converged"]
+    lb_r = np.array([x[1] for x in tr_ref]); lb_g = np.array([x[1] for x in tr_got])
+    np.testing.assert_allclose(lb_g, lb_r, rtol=1e-8)
+    np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
