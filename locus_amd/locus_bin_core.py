@@ -23,7 +23,7 @@ from scipy.special import digamma
 from . import elbo as E
 from . import update_vb as U
 from .comm import Comm
-from .locus_core import EPS_MACH, HostBase, _gather
+from .locus_core import EPS_MACH, HostBase, _gather, resolve_backend
 
 
 class BinHost(HostBase):
@@ -93,9 +93,10 @@ class BinEngine:
     """One GPU's shard of a binary-response model (link = 'logit' | 'probit')."""
 
     def __init__(self, link, px, Y_dev, Z, state, alpha_vb, sig2_alpha_vb, sig2_beta_vb, host,
-                 device):
+                 device, dv=None):
         import torch
-        from . import device as dv
+        if dv is None:
+            from . import device as dv
         assert link in ("logit", "probit")
         self.link, self.torch, self.dv = link, torch, dv
         self.px, self.Y, self.state, self.host, self.device = px, Y_dev, state, host, device
@@ -255,14 +256,12 @@ class BinEngine:
 
 def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb, sig2_beta_vb,
          tol, maxit, verbose, batch, full_output, debug, perm_fn, alpha_perm_fn, comm, device,
-         trace):
+         trace, _test_backend):
+    dv, device = resolve_backend(_test_backend, device)
     import torch
-    from . import device as dv
-    dv.require_gpu()
     if batch != "y":
         raise NotImplementedError("only the 'y' scheme is device-resident")
     comm = comm or Comm()
-    device = device or torch.device("cuda", torch.cuda.current_device())
     Y = np.asarray(Y, dtype=np.float64)
     X = np.asarray(X, dtype=np.float64)
     Z = np.asarray(Z, dtype=np.float64)
@@ -284,7 +283,7 @@ def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
         s2b_loc = np.asarray(sig2_beta_vb, dtype=np.float64)[:, k_lo:k_hi]
     else:
         s2a_loc, s2b_loc = sig2_alpha_vb, float(sig2_beta_vb)
-    eng = BinEngine(link, px, Y_dev, Z, state, alpha_loc, s2a_loc, s2b_loc, host, device)
+    eng = BinEngine(link, px, Y_dev, Z, state, alpha_loc, s2a_loc, s2b_loc, host, device, dv=dv)
     eng.initialise()
 
     converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
@@ -324,7 +323,7 @@ def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
 def locus_logit_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
                       sig2_beta_vb, tol, maxit, verbose=False, batch="y", full_output=False,
                       debug=False, perm_fn=None, alpha_perm_fn=None, comm=None, device=None,
-                      trace=None):
+                      trace=None, _test_backend=None):
     """R/locus_logistic_core.R:8-265 on the GPU.  Y has 1/2 subtracted, X standardised, Z holds
     the intercept / fixed covariates (n x q); alpha_vb, sig2_alpha_vb are q x d and
     sig2_beta_vb is p x d.  The reference's `chi_vb` argument is overwritten before its
@@ -332,15 +331,15 @@ def locus_logit_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_al
     alpha loop (R: sample(1:q), :79; 0-based here), `perm_fn(it)` the SNP sweep order."""
     return _run("logit", Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
                 sig2_beta_vb, tol, maxit, verbose, batch, full_output, debug, perm_fn,
-                alpha_perm_fn, comm, device, trace)
+                alpha_perm_fn, comm, device, trace, _test_backend)
 
 
 def locus_probit_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
                        sig2_beta_vb, tol, maxit, verbose=False, batch="y", full_output=False,
                        debug=False, perm_fn=None, alpha_perm_fn=None, comm=None, device=None,
-                       trace=None):
+                       trace=None, _test_backend=None):
     """R/locus_probit_core.R:8-250 on the GPU.  Y is 0/1, Z[:, 0] is the intercept (:13);
     sig2_alpha_vb is a length-q vector and sig2_beta_vb a scalar."""
     return _run("probit", Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
                 sig2_beta_vb, tol, maxit, verbose, batch, full_output, debug, perm_fn,
-                alpha_perm_fn, comm, device, trace)
+                alpha_perm_fn, comm, device, trace, _test_backend)

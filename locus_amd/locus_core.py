@@ -131,9 +131,10 @@ class IdentityHost(HostBase):
 class IdentityEngine:
     """One GPU's shard of the identity-link model."""
 
-    def __init__(self, px, Y_dev, state, host, device, cfg=None):
+    def __init__(self, px, Y_dev, state, host, device, cfg=None, dv=None):
         import torch
-        from . import device as dv
+        if dv is None:
+            from . import device as dv
         self.torch, self.dv = torch, dv
         self.px, self.Y, self.state, self.host, self.device = px, Y_dev, state, host, device
         self.n, self.d_loc = Y_dev.shape
@@ -191,6 +192,17 @@ class IdentityEngine:
         return out
 
 
+def resolve_backend(test_backend, device):
+    """(device layer, torch device).  The product always gets the HIP layer (and fails loudly
+    without a GPU); a test may inject an emulation of locus_amd.device on CPU tensors."""
+    import torch
+    if test_backend is not None:
+        return test_backend, torch.device("cpu")
+    from . import device as dv
+    dv.require_gpu()
+    return dv, device or torch.device("cuda", torch.cuda.current_device())
+
+
 def checkpoint_(it, checkpoint_path, gam_vb_fn, converged, lb_new, lb_old, om_vb, rate=100):
     """R/utils.R:316-336 (npz instead of RData): every `rate` iterations, keep the last two."""
     if checkpoint_path is not None and it % rate == 0:
@@ -210,21 +222,24 @@ def checkpoint_clean_up_(checkpoint_path):  # R/utils.R:339-352
 
 def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol, maxit,
                 anneal=None, verbose=False, batch="y", full_output=False, debug=True,
-                checkpoint_path=None, perm_fn=None, comm=None, device=None, trace=None):
+                checkpoint_path=None, perm_fn=None, comm=None, device=None, trace=None,
+                _test_backend=None):
     """R/locus_core.R:8-255 on the GPU.  Y (n x d) must be centred and X (n x p) standardised.
 
     `perm_fn(it)` supplies the sweep order of iteration `it` (float64, 0-based); by default
     numpy draws it (R: sample(0:(p-1)), :88).  With a DistComm every rank passes the FULL
     arrays and keeps only its response shard on its GPU; outputs are gathered on every rank.
+
+    `_test_backend` is a test hook, never set by the product: tests/cpu_device.py emulates the
+    device layer on CPU tensors so that the host arithmetic and the d-sharding can run under
+    gloo without a GPU.  Without it the HIP library is required (no fallback).
     """
+    dv, device = resolve_backend(_test_backend, device)
     import torch
-    from . import device as dv
-    dv.require_gpu()
     if batch != "y":
         raise NotImplementedError("only the 'y' scheme (coreLoop) is device-resident; "
                                   "coreBatch is available as locus_amd.coreBatch")
     comm = comm or Comm()
-    device = device or torch.device("cuda", torch.cuda.current_device())
     Y = np.asarray(Y, dtype=np.float64)
     X = np.asarray(X, dtype=np.float64)
     n, d = Y.shape
@@ -246,7 +261,7 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
     state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)
     state[0] = torch.from_numpy(np.ascontiguousarray(np.asarray(gam_vb)[:, k_lo:k_hi])).to(device)
     state[1] = torch.from_numpy(np.ascontiguousarray(np.asarray(mu_beta_vb)[:, k_lo:k_hi])).to(device)
-    eng = IdentityEngine(px, Y_dev, state, host, device)
+    eng = IdentityEngine(px, Y_dev, state, host, device, dv=dv)
     eng.initialise()
 
     if anneal is None:

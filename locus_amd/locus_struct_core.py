@@ -6,12 +6,12 @@ involves theta (W, the block matvecs, e_theta_) needs only rowSums(gam_vb), so i
 replicated host arithmetic on the all-reduced vector.
 """
 import numpy as np
-from scipy.special import digamma, log_ndtr
+from scipy.special import log_ndtr
 
 from . import elbo as E
 from . import update_vb as U
 from .comm import Comm
-from .locus_core import HostBase, IdentityEngine, _gather, _gather_vec
+from .locus_core import HostBase, IdentityEngine, _gather, _gather_vec, resolve_backend
 from .struct import StructBlocks, row_sums_W_struct_
 
 EPS_STRUCT = np.finfo(np.float64).eps ** 0.75  # R/elbo.R:94
@@ -94,16 +94,14 @@ class StructHost(HostBase):
 
 def locus_struct_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, list_struct,
                        tol, maxit, verbose=False, batch="y", full_output=False, debug=False,
-                       perm_fn=None, comm=None, device=None, trace=None):
+                       perm_fn=None, comm=None, device=None, trace=None, _test_backend=None):
     """R/locus_struct_core.R:8-184 on the GPU; Y centred, X standardised.  `list_struct` is
     what locus_amd.struct.set_struct returns.  See locus_core_ for perm_fn / comm."""
+    dv, device = resolve_backend(_test_backend, device)
     import torch
-    from . import device as dv
-    dv.require_gpu()
     if batch != "y":
         raise NotImplementedError("only the 'y' scheme (coreStructLoop) is implemented")
     comm = comm or Comm()
-    device = device or torch.device("cuda", torch.cuda.current_device())
     Y = np.asarray(Y, dtype=np.float64)
     X = np.asarray(X, dtype=np.float64)
     n, d = Y.shape
@@ -125,7 +123,7 @@ def locus_struct_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_v
     state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)
     state[0] = torch.from_numpy(np.ascontiguousarray(np.asarray(gam_vb)[:, k_lo:k_hi])).to(device)
     state[1] = torch.from_numpy(np.ascontiguousarray(np.asarray(mu_beta_vb)[:, k_lo:k_hi])).to(device)
-    eng = IdentityEngine(px, Y_dev, state, host, device)
+    eng = IdentityEngine(px, Y_dev, state, host, device, dv=dv)
     eng.initialise()
 
     converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
