@@ -119,8 +119,9 @@ int64_t locus_hip_packed_ld(int64_t n);
 int locus_hip_pack_x_dev(const double* X, int64_t n, int64_t p, double* Xp, double* xtx,
                          void* stream);
 
-/* Bytes of scratch a sweep over p covariates needs (step records, permutation check). */
-int64_t locus_hip_sweep_workspace_bytes(int64_t p);
+/* Bytes of scratch a sweep over p covariates of n rows needs (step records, permutation
+ * check, and the per-sweep block-packed copies of X the matrix-core kernel reads). */
+int64_t locus_hip_sweep_workspace_bytes(int64_t n, int64_t p);
 
 typedef struct locus_hip_sweep_args {
     int64_t n, p, d;            /* d = responses resident on this device            */
@@ -145,10 +146,12 @@ typedef struct locus_hip_sweep_args {
     double* state;              /* [3][p][d]: gam_vb, mu_beta_vb, beta_vb planes     */
     double* stats;              /* [4][d] or NULL: sum_j gam, sum_j m2_beta, sum_j beta^2,
                                    sum_i R^2 after the sweep                         */
-    void* workspace;            /* >= locus_hip_sweep_workspace_bytes(p)             */
+    void* workspace;            /* >= locus_hip_sweep_workspace_bytes(n, p)          */
     int64_t workspace_bytes;
     int64_t nsteps;             /* covariates to visit (0 or p = full sweep)          */
-    int32_t cfg[4];             /* NPL, C, S, G kernel geometry; all 0 = automatic    */
+    int32_t cfg[4];             /* NPL, C, S, G kernel geometry; all 0 = automatic;
+                                   NPL = -1: matrix-core kernel with C = tiles of 16 responses
+                                   per workgroup, S = waves, G = 16-row tiles per wave */
 } locus_hip_sweep_args;
 
 /* One CAVI sweep over the covariates in `shuffled_ind` order; logit = 0 runs the

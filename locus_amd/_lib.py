@@ -62,7 +62,7 @@ SIGNATURES = {
                                            _ptr, _dbl, _i64, _i64, _i64]),
     "locus_hip_packed_ld": (_i64, [_i64]),
     "locus_hip_pack_x_dev": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr]),
-    "locus_hip_sweep_workspace_bytes": (_i64, [_i64]),
+    "locus_hip_sweep_workspace_bytes": (_i64, [_i64, _i64]),
     "locus_hip_sweep_dev": (_int, [ctypes.POINTER(SweepArgs), _int, _ptr]),
     "locus_hip_sweep_status_dev": (_int, [_ptr, _i64, _ptr]),
     "locus_hip_sweep_config": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int32)]),

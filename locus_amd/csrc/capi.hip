@@ -75,10 +75,13 @@ int check_permutation(const double* ind, int64_t p)
     return 0;
 }
 
-size_t workspace_bytes(int64_t p)
+// step records: p rounded up to a multiple of 48 (every prefetch depth of the vector kernel,
+// whole blocks of 16 for the matrix-core kernel) plus a readable tail
+size_t step_slots(int64_t p) { return ((size_t)p + 47) / 48 * 48 + 32; }
+
+size_t small_workspace_bytes(int64_t p)
 {
-    const size_t nsteps_pad = ((size_t)p + 11) / 12 * 12;
-    size_t b = sizeof(StepRec) * (nsteps_pad + 16);  // step records
+    size_t b = sizeof(StepRec) * step_slots(p);
     b = (b + 255) / 256 * 256;
     b += sizeof(int) * (size_t)p;  // visited[]
     b = (b + 255) / 256 * 256;
@@ -86,24 +89,30 @@ size_t workspace_bytes(int64_t p)
     return b;
 }
 
+size_t workspace_bytes(int64_t n, int64_t p)
+{
+    return small_workspace_bytes(p) + mfma_workspace_bytes(n, p);
+}
+
 struct WsView {
     StepRec* steps;
     int* visited;
     int* err;
+    void* xb;  // block-packed X of the matrix-core kernel
 };
 
 WsView carve(void* ws, int64_t p)
 {
-    const size_t nsteps_pad = ((size_t)p + 11) / 12 * 12;
     char* c = static_cast<char*>(ws);
     WsView v;
     v.steps = reinterpret_cast<StepRec*>(c);
-    size_t b = sizeof(StepRec) * (nsteps_pad + 16);
+    size_t b = sizeof(StepRec) * step_slots(p);
     b = (b + 255) / 256 * 256;
     v.visited = reinterpret_cast<int*>(c + b);
     b += sizeof(int) * (size_t)p;
     b = (b + 255) / 256 * 256;
     v.err = reinterpret_cast<int*>(c + b);
+    v.xb = c + b + 256;
     return v;
 }
 
@@ -120,13 +129,15 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
     else
         LOCUS_REQUIRE(a->scale && a->hinv && a->cst && a->s2k,
                       "sweep: identity family needs scale, hinv, cst, s2k");
-    LOCUS_REQUIRE((size_t)a->workspace_bytes >= workspace_bytes(a->p), "sweep: workspace too small");
+    LOCUS_REQUIRE((size_t)a->workspace_bytes >= workspace_bytes(a->n, a->p),
+                  "sweep: workspace too small");
     const int64_t nsteps = (a->nsteps <= 0 || a->nsteps > a->p) ? a->p : a->nsteps;
 
     SweepConfig cfg;
-    if (a->cfg[0] > 0) {
+    if (a->cfg[0] != 0) {
         cfg = SweepConfig{a->cfg[0], a->cfg[1], a->cfg[2], a->cfg[3]};
-        LOCUS_REQUIRE((int64_t)cfg.NPL * cfg.S * 64 >= a->n && cfg.C >= 1 && cfg.S >= 1 && cfg.G >= 1,
+        LOCUS_REQUIRE(cfg.C >= 1 && cfg.S >= 1 && cfg.G >= 1 &&
+                          (cfg.NPL < 0 || (int64_t)cfg.NPL * cfg.S * 64 >= a->n),
                       "sweep: bad explicit geometry");
     } else {
         rc = choose_sweep_config((int)a->n, (int)a->d, logit != 0, &cfg);
@@ -136,7 +147,7 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
     WsView ws = carve(a->workspace, a->p);
     const int nsteps_pad = (int)((nsteps + 11) / 12 * 12);
     rc = build_steps(a->shuffled_ind, a->lo, a->l1, a->xtx, ws.steps, ws.visited, ws.err, (int)a->p,
-                     (int)nsteps, nsteps_pad + 16, st);
+                     (int)nsteps, (int)step_slots(nsteps), st);
     if (rc) return rc;
 
     SweepParams prm;
@@ -162,6 +173,10 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
     prm.R = a->R;
     prm.state = a->state;
     prm.st = a->stats;
+    if (cfg.NPL < 0) {
+        LOCUS_REQUIRE(!logit, "sweep: the matrix-core kernel covers the identity family only");
+        return run_mfma_sweep(prm, cfg, ws.xb, mfma_workspace_bytes(a->n, a->p), st);
+    }
     return launch_sweep(prm, cfg, logit != 0, st);
 }
 
@@ -266,7 +281,7 @@ int run_loop(int kind, const double* X, const double* Y, double* gam, const doub
         if ((rc = upload(dcst, h_cst.data(), (size_t)d))) return rc;
         if ((rc = upload(ds2k, h_s2k.data(), (size_t)d))) return rc;
     }
-    if ((rc = dws.alloc(workspace_bytes(p)))) return rc;
+    if ((rc = dws.alloc(workspace_bytes(n, p)))) return rc;
 
     locus_hip_sweep_args a;
     memset(&a, 0, sizeof(a));
@@ -275,7 +290,7 @@ int run_loop(int kind, const double* X, const double* Y, double* gam, const doub
     a.scale = dscale.d(); a.hinv = dhinv.d(); a.cst = dcst.d(); a.s2k = ds2k.d(); a.cfac = c;
     a.s2 = ds2.d(); a.xwx = dxwx.d(); a.W2 = dW2.d(); a.half_lsi = log_sig2_inv / 2;
     a.R = dR.d(); a.state = dstate.d(); a.stats = nullptr;
-    a.workspace = dws.p; a.workspace_bytes = (int64_t)workspace_bytes(p); a.nsteps = p;
+    a.workspace = dws.p; a.workspace_bytes = (int64_t)workspace_bytes(n, p); a.nsteps = p;
     if ((rc = sweep_dev(&a, kind == 2, st))) return rc;
 
     // back to the reference's layout: mat_x_m1 from the residual, planes transposed back
@@ -498,7 +513,10 @@ int locus_hip_pack_x_dev(const double* X, int64_t n, int64_t p, double* Xp, doub
     return pack_x(X, Xp, xtx, (int)n, (int)p, (int)locus_hip_packed_ld(n), (hipStream_t)stream);
 }
 
-int64_t locus_hip_sweep_workspace_bytes(int64_t p) { return (int64_t)workspace_bytes(p < 1 ? 1 : p); }
+int64_t locus_hip_sweep_workspace_bytes(int64_t n, int64_t p)
+{
+    return (int64_t)workspace_bytes(n < 1 ? 1 : n, p < 1 ? 1 : p);
+}
 
 int locus_hip_sweep_dev(const locus_hip_sweep_args* args, int logit, void* stream)
 {

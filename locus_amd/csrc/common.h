@@ -80,7 +80,12 @@ struct SweepConfig {
     int G;    // column groups per workgroup
 };
 
+// NPL == -1 selects the matrix-core kernel (mfma_sweep_kernel.h); then C = tiles of 16 responses
+// per workgroup (1..3), S = waves per workgroup (4, 8, 16), G = 16-row tiles per wave.
 int choose_sweep_config(int n, int d, bool logit, SweepConfig* cfg);
+size_t mfma_workspace_bytes(int64_t n, int64_t p);
+int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
+                   hipStream_t st);
 int launch_sweep(const SweepParams& prm, const SweepConfig& cfg, bool logit, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepConfig& cfg);
 

@@ -78,7 +78,8 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
     }
     if (const char* env = getenv("LOCUS_HIP_SWEEP_CFG")) {  // "NPL,C,S,G" (tuning / tests)
         SweepConfig c{};
-        if (sscanf(env, "%d,%d,%d,%d", &c.NPL, &c.C, &c.S, &c.G) == 4 && c.NPL * c.S * 64 >= n) {
+        if (sscanf(env, "%d,%d,%d,%d", &c.NPL, &c.C, &c.S, &c.G) == 4 &&
+            (c.NPL < 0 ? (!logit && 16 * c.G * c.S >= n) : (c.NPL * c.S * 64 >= n))) {
             *out = c;
             return 0;
         }

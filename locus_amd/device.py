@@ -68,7 +68,7 @@ class Sweeper:
     def __init__(self, px, d, device, cfg=None):
         self.px = px
         self.n, self.p, self.d = px.n, px.p, int(d)
-        nbytes = int(_lib.lib().locus_hip_sweep_workspace_bytes(self.p))
+        nbytes = int(_lib.lib().locus_hip_sweep_workspace_bytes(self.n, self.p))
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         self.cfg = cfg
         self._keep = None

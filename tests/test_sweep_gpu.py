@@ -78,3 +78,35 @@ def test_two_sweeps_in_a_row_deterministic(hip):
     b = call_variant(hip, "identity", inp)
     for k in a:
         assert np.array_equal(a[k], b[k]), f"{k} differs run to run"
+
+
+# matrix-core kernel, explicit geometries -1,T,S,KW4 (T tiles of 16 responses per workgroup,
+# S waves, KW4 16-row tiles per wave): ragged rows / responses / last block of the sweep
+MFMA_GEOMS = ["-1,1,4,1", "-1,2,4,1", "-1,3,4,2", "-1,1,8,2", "-1,2,4,4", "-1,3,4,4", "-1,1,4,8",
+              "-1,2,8,4", "-1,1,4,16", "-1,3,4,16", "-1,2,4,16", "-1,2,4,8", "-1,3,4,8"]
+
+
+@pytest.mark.parametrize("geom", MFMA_GEOMS)
+def test_mfma_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
+    _, t, s, kw4 = map(int, geom.split(","))
+    n = 16 * kw4 * s - 5
+    p, d = 53, 16 * t + 16 * t + 7    # 3 blocks + 5 steps; partial last workgroup / tile
+    inp = inputs_for("identity", n, p, d, seed=21)
+    ref = call_variant(oracle, "identity", inp)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", geom)
+    got = call_variant(hip, "identity", inp)
+    assert_parity(got, ref, what=f"identity mfma geom {geom}")
+
+
+@pytest.mark.parametrize("variant", ["identity", "z", "struct", "probit"])
+@pytest.mark.parametrize("shape", [(200, 500, 20), (1000, 64, 41), (100, 16, 3), (64, 7, 1)])
+def test_mfma_sweep_variants(oracle, hip, variant, shape, monkeypatch):
+    n, p, d = shape
+    kw4 = 1
+    while 64 * kw4 < n:
+        kw4 *= 2
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-1,{1 if d <= 16 else 2},4,{kw4}")
+    inp = inputs_for(variant, n, p, d, seed=n + p + d, c=0.6 if variant == "identity" else 1.0)
+    ref = call_variant(oracle, variant, inp)
+    got = call_variant(hip, variant, inp)
+    assert_parity(got, ref, what=f"{variant} {shape} mfma")
