@@ -14,21 +14,22 @@ int launch_mfma_sweep_t3(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStr
 // ---------------------------------------------------------------------------
 // One workgroup per block of 16 consecutive sweep steps: gathers the 16 columns of the packed
 // X (128 rows at a time through LDS) and writes them in the two MFMA operand orders
-//   XBd[b][g][l]      = X[4 g + (l >> 4)][j_{l & 15}]              (A operand of G = X_J' R)
-//   XBu[b][t][kk][l]  = X[16 t + (l & 15)][j_{4 kk + (l >> 4)}]    (A operand of R += X_J delta)
-// plus the block's Gram matrix gram[b][t][s] = X_{j_t}' X_{j_s}.  Rows >= n are zero.
+//   dot operand g:        l -> X[4 g + (l >> 4)][j_{l & 15}]            (A of G = X_J' R)
+//   update operand (t,kk): l -> X[16 t + (l & 15)][j_{4 kk + (l >> 4)}]  (A of R += X_J delta)
+// stored as XB[b][wave][2][KW][64] (KW = k-steps of 4 rows per wave): the order in which wave
+// `wave` consumes them.  Also the block's Gram matrix gram[b][t][s] = X_{j_t}' X_{j_s}.  Rows >= n are zero.
 // Bandwidth-bound: reads p*ld, writes 2*p*rows_pad doubles per sweep.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ steps,
-                   double* __restrict__ XBd, double* __restrict__ XBu, double* __restrict__ gram,
-                   int ld, int rows_pad)
+                   double* __restrict__ XB, double* __restrict__ gram, int ld, int rows_pad,
+                   int KW)
 {
     __shared__ double xt[16][130];
     __shared__ int js[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid < 16) js[tid] = steps[16 * b + tid].j;
-    const size_t ngs = (size_t)rows_pad >> 2, nts = (size_t)rows_pad >> 4;
+    const size_t blk = (size_t)rows_pad * 32;  // doubles per block (both operand sets)
     const int gt = tid >> 4, gs = tid & 15;
     double gacc = 0.0;
     for (int c0 = 0; c0 < rows_pad; c0 += 128) {
@@ -46,12 +47,16 @@ pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ st
             const int o = tid + 256 * i;
             const int ln = o & 63;
             const int gl = o >> 6;  // k-step inside the chunk
-            if (4 * gl < rows_here)
-                XBd[((size_t)b * ngs + (c0 >> 2) + gl) * 64 + ln] = xt[ln & 15][4 * gl + (ln >> 4)];
-            const int tl = o >> 8, kk = (o >> 6) & 3;  // tile inside the chunk, k-slice
-            if (16 * tl < rows_here)
-                XBu[(((size_t)b * nts + (c0 >> 4) + tl) * 4 + kk) * 64 + ln] =
-                    xt[4 * kk + (ln >> 4)][16 * tl + (ln & 15)];
+            if (4 * gl < rows_here) {
+                // global k-step -> (wave, k-step in wave); update operands use the same index
+                // (4 * tile + kk) and sit KW operands after the wave's dot operands
+                const int gg = (c0 >> 2) + gl;
+                const int w = gg / KW, gi = gg - w * KW;
+                double* o_d = XB + (size_t)b * blk + ((size_t)w * 2 * KW + gi) * 64 + ln;
+                o_d[0] = xt[ln & 15][4 * gl + (ln >> 4)];
+                const int tl = gl >> 2, kk = gl & 3;  // 16-row tile inside the chunk, k-slice
+                o_d[(size_t)KW * 64] = xt[4 * kk + (ln >> 4)][16 * tl + (ln & 15)];
+            }
         }
         for (int rr = 0; rr < 128; ++rr) gacc = fma(xt[gt][rr], xt[gs][rr], gacc);
     }
@@ -94,26 +99,25 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
         return LOCUS_HIP_EINVAL;
     }
     const int nblk = (prm.nsteps + 15) / 16;
-    const size_t xb = (size_t)nblk * rows_pad * 16;  // doubles per packed copy
-    if (sizeof(double) * (2 * xb + (size_t)nblk * 256) + 512 > xb_bytes) {
+    const size_t xb = (size_t)nblk * rows_pad * 32;  // doubles of the packed operand stream
+    if (sizeof(double) * (xb + (size_t)nblk * 256) + 512 > xb_bytes) {
         set_error("mfma sweep: workspace too small");
         return LOCUS_HIP_EINVAL;
     }
     char* base = static_cast<char*>(xb_ws);
     base += (256 - ((uintptr_t)base & 255)) & 255;
-    double* XBd = reinterpret_cast<double*>(base);
-    double* XBu = XBd + xb;
-    double* gram = XBu + xb;
+    double* XB = reinterpret_cast<double*>(base);
+    double* gram = XB + xb;
 
-    hipLaunchKernelGGL(pack_blocks_kernel, dim3(nblk), dim3(256), 0, st, prm.Xp, prm.steps, XBd, XBu,
-                       gram, prm.ld, rows_pad);
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3(nblk), dim3(256), 0, st, prm.Xp, prm.steps, XB, gram,
+                       prm.ld, rows_pad, 4 * KW4);
     LOCUS_HIP_CHECK(hipGetLastError());
 
     MfmaSweepParams mp;
     mp.n = prm.n; mp.p = prm.p; mp.d = prm.d;
     mp.nblk = nblk; mp.nsteps = prm.nsteps; mp.rows_pad = rows_pad;
     mp.steps = prm.steps; mp.err = prm.err;
-    mp.XBd = XBd; mp.XBu = XBu; mp.gram = gram;
+    mp.XB = XB; mp.gram = gram;
     mp.scale = prm.scale; mp.hinv = prm.hinv; mp.cst = prm.cst; mp.s2k = prm.s2k;
     mp.cfac = prm.cfac;
     mp.R = prm.R; mp.state = prm.state; mp.st = prm.st;

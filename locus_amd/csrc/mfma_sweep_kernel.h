@@ -39,8 +39,8 @@ struct MfmaSweepParams {
     int rows_pad;        // 16 * KW4 * S  (>= n)
     const StepRec* steps;  // [16 * nblk + 16]
     const int* err;
-    const double* XBd;   // [nblk][rows_pad/4][64]      dot operand order
-    const double* XBu;   // [nblk][rows_pad/16][4][64]  update operand order
+    const double* XB;    // [nblk][S][2][KW][64]: per block and wave, the KW dot operands
+                         // (A of G = X_J' R) then the KW update operands (A of R += X_J delta)
     const double* gram;  // [nblk][16][16]              X_J'X_J
     const double* scale; // per-response constants, as SweepParams
     const double* hinv;
@@ -118,10 +118,11 @@ mfma_sweep_kernel(const MfmaSweepParams P)
     }
     double acc_g = 0.0, acc_m2 = 0.0, acc_b2 = 0.0;
 
-    const size_t ngs = (size_t)P.rows_pad >> 2;            // k-steps per block in XBd
-    const double* xd_base = P.XBd + ((size_t)s * KW) * 64 + lane;
-    const double* xu_base = P.XBu + ((size_t)s * KW4) * 256 + lane;
-    const size_t blk_stride = ngs * 64;                    // doubles per block in XBd == XBu
+    // This wave's X operands form ONE stream in consumption order: 2 KW operands of 64
+    // doubles per block, then a jump over the other waves' share.  A single running
+    // pointer keeps the address arithmetic out of the SGPR file.
+    const double* xp = P.XB + ((size_t)s * 2 * KW) * 64 + lane;
+    const size_t blk_skip = (size_t)(S - 1) * 2 * KW * 64;
     const int nb_per_wave = 16 / S;                        // beta_old loads per wave per block (S >= 4)
 
     // ---- block 0: beta_old and Gram straight to LDS (parity 0) -----------------------
@@ -134,12 +135,13 @@ mfma_sweep_kernel(const MfmaSweepParams P)
     // X ring: first operands of block 0's dot phase
     double ring[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) ring[i] = xd_base[(size_t)i * 64];
+    for (int i = 0; i < NR; ++i) {
+        ring[i] = *xp;
+        xp += 64;
+    }
 
     for (int b = 0; b < P.nblk; ++b) {
         const int par = b & 1;
-        const double* xd = xd_base + (size_t)b * blk_stride;
-        const double* xu = xu_base + (size_t)b * blk_stride;
         const bool more = (b + 1 < P.nblk);
 
         // prefetch for block b + 1: beta_old (this wave's share) and the Gram matrix
@@ -161,11 +163,9 @@ mfma_sweep_kernel(const MfmaSweepParams P)
 #pragma unroll
         for (int g = 0; g < KW; ++g) {
             const double a = ring[g % NR];
-            // refill: later dot operands, then the first update operands
-            if (g + NR < KW)
-                ring[g % NR] = xd[(size_t)(g + NR) * 64];
-            else
-                ring[g % NR] = xu[(size_t)(g + NR - KW) * 64];
+            ring[g % NR] = *xp;  // operand g + NR of this block's stream
+            xp += 64;
+            if ((g & 7) == 7) asm volatile("" : "+v"(xp));
 #pragma unroll
             for (int tau = 0; tau < T; ++tau)
                 acc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rv[tau][g >> 2][g & 3], acc[tau],
@@ -250,10 +250,12 @@ mfma_sweep_kernel(const MfmaSweepParams P)
         for (int g = 0; g < KW; ++g) {  // g = 4 * tile + kk
             const int slot = (g + KW) % NR;
             const double a = ring[slot];
-            if (g + NR < KW)
-                ring[slot] = xu[(size_t)(g + NR) * 64];
-            else if (more)
-                ring[slot] = xd[blk_stride + (size_t)(g + NR - KW) * 64];
+            if (g + NR == KW) xp += blk_skip;  // the stream continues in the next block
+            if (g + NR < KW || more) {
+                ring[slot] = *xp;
+                xp += 64;
+            }
+            if ((g & 7) == 7) asm volatile("" : "+v"(xp));
 #pragma unroll
             for (int tau = 0; tau < T; ++tau)
                 rv[tau][g >> 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[tau][g & 3],
