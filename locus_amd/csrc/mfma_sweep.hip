@@ -16,8 +16,8 @@ int launch_mfma_sweep_t3(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStr
 // X (128 rows at a time through LDS) and writes them in the two MFMA operand orders
 //   dot operand g:        l -> X[4 g + (l >> 4)][j_{l & 15}]            (A of G = X_J' R)
 //   update operand (t,kk): l -> X[16 t + (l & 15)][j_{4 kk + (l >> 4)}]  (A of R += X_J delta)
-// stored as XB[b][wave][2][KW][64] (KW = k-steps of 4 rows per wave): the order in which wave
-// `wave` consumes them.  Also the block's Gram matrix gram[b][t][s] = X_{j_t}' X_{j_s}.  Rows >= n are zero.
+// stored as XB[b][wave][KW][64][2] (KW = k-steps of 4 rows per wave; consecutive operands paired
+// per lane): the order in which wave `wave` consumes them.  Also the block's Gram matrix gram[b][t][s] = X_{j_t}' X_{j_s}.  Rows >= n are zero.
 // Bandwidth-bound: reads p*ld, writes 2*p*rows_pad doubles per sweep.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -52,10 +52,12 @@ pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ st
                 // (4 * tile + kk) and sit KW operands after the wave's dot operands
                 const int gg = (c0 >> 2) + gl;
                 const int w = gg / KW, gi = gg - w * KW;
-                double* o_d = XB + (size_t)b * blk + ((size_t)w * 2 * KW + gi) * 64 + ln;
-                o_d[0] = xt[ln & 15][4 * gl + (ln >> 4)];
+                // operand o of the wave's stream -> pair o >> 1, element o & 1 of lane ln
+                double* wb = XB + (size_t)b * blk + (size_t)w * KW * 128 + ln * 2;
+                wb[(size_t)(gi >> 1) * 128 + (gi & 1)] = xt[ln & 15][4 * gl + (ln >> 4)];
                 const int tl = gl >> 2, kk = gl & 3;  // 16-row tile inside the chunk, k-slice
-                o_d[(size_t)KW * 64] = xt[4 * kk + (ln >> 4)][16 * tl + (ln & 15)];
+                const int ou = KW + gi;
+                wb[(size_t)(ou >> 1) * 128 + (ou & 1)] = xt[4 * kk + (ln >> 4)][16 * tl + (ln & 15)];
             }
         }
         for (int rr = 0; rr < 128; ++rr) gacc = fma(xt[gt][rr], xt[gs][rr], gacc);
@@ -80,7 +82,7 @@ size_t mfma_workspace_bytes(int64_t n, int64_t p)
 
 size_t mfma_lds_bytes(int T, int S)
 {
-    return sizeof(double) * (2 * (size_t)S * T * 256 + 2 * 16 * 64 + 2 * 256 + 16 * 64);
+    return sizeof(double) * (2 * (size_t)S * T * 256 + 2 * 16 * 64 + 2 * 256 + 2 * 32 + 16 * 64);
 }
 
 // cfg: C = T (tiles per workgroup), S = waves per workgroup, G = KW4 (16-row tiles per wave)

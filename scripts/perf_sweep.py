@@ -56,7 +56,18 @@ def main():
         cfg_used = (_lib.ctypes.c_int32 * 4)()
         _lib.lib().locus_hip_sweep_config(n, d, int(logit), cfg_used)
         upd = nsteps * d / (t * 1e-3)
-        if "diag" in _lib.LIB_PATH:
+        if "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0:
+            import ctypes
+            fn = getattr(ctypes.CDLL(_lib.LIB_PATH), f"locus_hip_diag_read_mfma_stamps_{cfg[1]}")
+            nwg = min(4096, (d + 16 * cfg[1] - 1) // (16 * cfg[1]))
+            buf = (ctypes.c_ulonglong * (8 * nwg))()
+            fn(buf, 8 * nwg)
+            a = np.array(buf, dtype=np.float64).reshape(nwg, 8)[:, :7] / ((nsteps + 15) // 16)
+            names = ["dot", "part->lds", "barrier", "next->lds", "chain", "update", "prefetch-issue"]
+            print("   cycles/block (median over WGs, wave 0): " +
+                  " ".join(f"{nm}={v:.0f}" for nm, v in zip(names, np.median(a, axis=0))) +
+                  f" total={np.median(a.sum(axis=1)):.0f}")
+        elif "diag" in _lib.LIB_PATH:
             import ctypes
             c = cfg or tuple(cfg_used)
             f = getattr(_lib.lib(), f"locus_hip_diag_read_stamps_{c[0]}_{int(logit)}")
