@@ -9,7 +9,6 @@ namespace locus {
 
 int launch_mfma_sweep_t1(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
 int launch_mfma_sweep_t2(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
-int launch_mfma_sweep_t3(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
 
 // ---------------------------------------------------------------------------
 // One workgroup per block of 16 consecutive sweep steps: gathers the 16 columns of the packed
@@ -22,13 +21,17 @@ int launch_mfma_sweep_t3(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStr
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ steps,
-                   double* __restrict__ XB, double* __restrict__ gram, int ld, int rows_pad,
-                   int KW)
+                   double* __restrict__ XB, double* __restrict__ gram, int* __restrict__ jidx,
+                   int ld, int rows_pad, int KW)
 {
     __shared__ double xt[16][130];
     __shared__ int js[16];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid < 16) js[tid] = steps[16 * b + tid].j;
+    if (tid < 16) {
+        js[tid] = steps[16 * b + tid].j;
+        jidx[16 * b + tid] = js[tid];
+        if (b == gridDim.x - 1) jidx[16 * (b + 1) + tid] = 0;  // readable tail (prefetch)
+    }
     const size_t blk = (size_t)rows_pad * 32;  // doubles per block (both operand sets)
     const int gt = tid >> 4, gs = tid & 15;
     double gacc = 0.0;
@@ -56,7 +59,7 @@ pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ st
                 double* wb = XB + (size_t)b * blk + (size_t)w * KW * 128 + ln * 2;
                 wb[(size_t)(gi >> 1) * 128 + (gi & 1)] = xt[ln & 15][4 * gl + (ln >> 4)];
                 const int tl = gl >> 2, kk = gl & 3;  // 16-row tile inside the chunk, k-slice
-                const int ou = KW + gi;
+                const int ou = KW + kk * (KW >> 2) + (gi >> 2);  // k-slice major, row tile minor
                 wb[(size_t)(ou >> 1) * 128 + (ou & 1)] = xt[4 * kk + (ln >> 4)][16 * tl + (ln & 15)];
             }
         }
@@ -77,7 +80,8 @@ size_t mfma_workspace_bytes(int64_t n, int64_t p)
 {
     const size_t nblk = ((size_t)p + 15) / 16;
     const size_t rp = mfma_rows_pad_max(n);
-    return sizeof(double) * (2 * nblk * rp * 16 + nblk * 256) + 512;
+    return sizeof(double) * (2 * nblk * rp * 16 + (nblk + 1) * 256) + sizeof(int) * 16 * (nblk + 1) +
+           1024;
 }
 
 size_t mfma_lds_bytes(int T, int S)
@@ -90,9 +94,9 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
                    hipStream_t st)
 {
     const int T = cfg.C, S = cfg.S, KW4 = cfg.G;
-    if (T < 1 || T > 3 || (S != 4 && S != 8) ||
+    if (T < 1 || T > 2 || (S != 4 && S != 8) ||
         (KW4 != 1 && KW4 != 2 && KW4 != 4 && KW4 != 8 && KW4 != 16)) {
-        set_error("mfma sweep: bad geometry (T in 1..3, S in {4,8}, KW4 in {1,2,4,8,16})");
+        set_error("mfma sweep: bad geometry (T in 1..2, S in {4,8}, KW4 in {1,2,4,8,16})");
         return LOCUS_HIP_EINVAL;
     }
     const int rows_pad = 16 * KW4 * S;
@@ -102,24 +106,26 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
     }
     const int nblk = (prm.nsteps + 15) / 16;
     const size_t xb = (size_t)nblk * rows_pad * 32;  // doubles of the packed operand stream
-    if (sizeof(double) * (xb + (size_t)nblk * 256) + 512 > xb_bytes) {
+    if (sizeof(double) * (xb + ((size_t)nblk + 1) * 256) + sizeof(int) * 16 * ((size_t)nblk + 1) +
+            512 > xb_bytes) {
         set_error("mfma sweep: workspace too small");
         return LOCUS_HIP_EINVAL;
     }
     char* base = static_cast<char*>(xb_ws);
     base += (256 - ((uintptr_t)base & 255)) & 255;
     double* XB = reinterpret_cast<double*>(base);
-    double* gram = XB + xb;
+    double* gram = XB + xb;                                  // [nblk + 1][256] (tail: prefetch)
+    int* jidx = reinterpret_cast<int*>(gram + ((size_t)nblk + 1) * 256);
 
     hipLaunchKernelGGL(pack_blocks_kernel, dim3(nblk), dim3(256), 0, st, prm.Xp, prm.steps, XB, gram,
-                       prm.ld, rows_pad, 4 * KW4);
+                       jidx, prm.ld, rows_pad, 4 * KW4);
     LOCUS_HIP_CHECK(hipGetLastError());
 
     MfmaSweepParams mp;
     mp.n = prm.n; mp.p = prm.p; mp.d = prm.d;
     mp.nblk = nblk; mp.nsteps = prm.nsteps; mp.rows_pad = rows_pad;
     mp.steps = prm.steps; mp.err = prm.err;
-    mp.XB = XB; mp.gram = gram;
+    mp.XB = XB; mp.gram = gram; mp.jidx = jidx;
     mp.scale = prm.scale; mp.hinv = prm.hinv; mp.cst = prm.cst; mp.s2k = prm.s2k;
     mp.cfac = prm.cfac;
     mp.R = prm.R; mp.state = prm.state; mp.st = prm.st;
@@ -129,8 +135,7 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
     const size_t lds = mfma_lds_bytes(T, S);
     switch (T) {
         case 1: return launch_mfma_sweep_t1(mp, KW4, grid, block, lds, st);
-        case 2: return launch_mfma_sweep_t2(mp, KW4, grid, block, lds, st);
-        default: return launch_mfma_sweep_t3(mp, KW4, grid, block, lds, st);
+        default: return launch_mfma_sweep_t2(mp, KW4, grid, block, lds, st);
     }
 }
 

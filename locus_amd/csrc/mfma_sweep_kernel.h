@@ -24,11 +24,28 @@
 // Per block: dot MFMAs -> partial G to LDS -> ONE barrier -> every wave runs the 16-step
 // chain redundantly (lane = response) -> deltas through LDS -> update MFMAs.
 #pragma once
+#include <utility>
+
 #include "common.h"
+#include "fastmath.h"
 
 namespace locus {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N - 1>).  Register arrays
+// indexed inside must see true constants (a `#pragma unroll` loop whose trip count depends on
+// an outer unrolled index was compiled to movrel loops).
+template <class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f)
+{
+    if constexpr (N > 0) sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 constexpr int kBlk = 16;  // covariates per block (M of the MFMA)
 
@@ -43,6 +60,7 @@ struct MfmaSweepParams {
                          // (A of G = X_J' R) then the KW update operands (A of R += X_J delta),
                          // consecutive operands paired per lane (one 16-byte load = 2 operands)
     const double* gram;  // [nblk][16][16]              X_J'X_J
+    const int* jidx;     // [16 * nblk + 16]            covariate index of every step
     const double* scale; // per-response constants, as SweepParams
     const double* hinv;
     const double* cst;
@@ -77,59 +95,38 @@ __device__ unsigned long long g_mfma_stamps[8 * 4096];
 #define MSTAMP(k) do { } while (0)
 #endif
 
-// exp(x) for x <= 0, to < 1 ulp of truncation error and a few ulp of rounding: k = rint(x log2 e),
-// r = x - k ln 2 (two-term Cody-Waite), degree-12 Taylor polynomial in Horner form, ldexp.
-// 20 instructions with no branches and no table; at one wave per SIMD every fp64 VALU
-// instruction costs 8 issue cycles, so the instruction COUNT of the chain is what matters.
-__device__ __forceinline__ double exp_nonpos(double x)
-{
-    x = fmax(x, -800.0);  // exp underflows to 0 below -745.2; keeps k in int range
-    const double k = __builtin_rint(x * 1.4426950408889634074);
-    double r = fma(k, -6.93147180369123816490e-01, x);
-    r = fma(k, -1.90821492927058770002e-10, r);
-    double p = 2.08767569878680989792e-09;               // 1/12!
-    p = fma(p, r, 2.50521083854417187751e-08);           // 1/11!
-    p = fma(p, r, 2.75573192239858906526e-07);           // 1/10!
-    p = fma(p, r, 2.75573192239858906526e-06);           // 1/9!
-    p = fma(p, r, 2.48015873015873015873e-05);           // 1/8!
-    p = fma(p, r, 1.98412698412698412698e-04);           // 1/7!
-    p = fma(p, r, 1.38888888888888888889e-03);           // 1/6!
-    p = fma(p, r, 8.33333333333333333333e-03);           // 1/5!
-    p = fma(p, r, 4.16666666666666666667e-02);           // 1/4!
-    p = fma(p, r, 1.66666666666666666667e-01);           // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return __builtin_ldexp(p, (int)k);
-}
+// One update MFMA slot: row tile `i` of k-slice `kk` (covariates 4 kk .. 4 kk + 3 of the block),
+// operand number KW + kk * KW4 + i of the wave's stream for this block.
+#define LOCUS_UPD_SLOT(kk, i)                                                                  \
+    do {                                                                                       \
+        constexpr int o_ = KW + (kk) * KW4 + (i);      /* operand index in the block stream */  \
+        constexpr int sl_ = (o_ % NR) >> 1;                                                    \
+        const double a_ = (o_ & 1) ? ring[sl_].y : ring[sl_].x;                                \
+        if constexpr ((o_ & 1) != 0) {                                                         \
+            if constexpr (o_ + NR - 1 == 2 * KW) xp += blk_skip;                               \
+            if (o_ + NR - 1 < 2 * KW || more) {                                                \
+                ring[sl_] = *xp;                                                               \
+                xp += 64;                                                                      \
+            }                                                                                  \
+        }                                                                                      \
+        sfor<T>([&](auto tc_) {                                                                \
+            constexpr int tau_ = decltype(tc_)::value;                                         \
+            rv[tau_][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bop[tau_], rv[tau_][i], 0,  \
+                                                               0, 0);                          \
+        });                                                                                    \
+    } while (0)
 
-// num / den for den in [1, 2], num in [0, 1]: v_rcp_f64 + two Newton steps + one residual
-// correction (no scaling / fix-up needed in this range).
-__device__ __forceinline__ double div_1to2(double num, double den)
-{
-    double rcp = __builtin_amdgcn_rcp(den);
-    rcp = fma(fma(-den, rcp, 1.0), rcp, rcp);
-    rcp = fma(fma(-den, rcp, 1.0), rcp, rcp);
-    const double qv = num * rcp;
-    return fma(fma(-den, qv, num), rcp, qv);
-}
-
-// Register homes.  In a kernel that uses AGPRs the compiler selects the MFMA form whose
-// accumulator (C/D) operands are AGPRs; A/B operands may be VGPRs or AGPRs.  A wave can hold
-// 256 AGPRs = two tiles of 16 responses x 256 rows as accumulators.  The third tile (T = 3)
-// therefore lives in VGPRs as plain doubles: it is a B operand in the dot phase as it is,
-// and its rank-16 update is accumulated into a zeroed AGPR tile and added with vector adds
-// (1/16 of the flops of its MFMAs).
 template <int T, int KW4, int S>
 __global__ void __launch_bounds__(64 * S)
 mfma_sweep_kernel(const MfmaSweepParams P)
 {
-    static_assert(T >= 1 && T <= 3, "1..3 response tiles per workgroup");
+    static_assert(T >= 1 && T <= 2, "1 or 2 response tiles per workgroup");
     static_assert(S == 4 || S == 8, "4 or 8 waves per workgroup");
     constexpr int KW = 4 * KW4;          // k-steps (4 rows each) per wave
     constexpr int NR = (KW < kRing) ? KW : kRing;  // operands in flight (even)
     constexpr int NR2 = NR / 2;
     constexpr int NBW = 16 / S;          // beta_old loads per wave and block
+    static_assert((2 * KW) % NR == 0 && NR % 2 == 0, "ring must divide the block stream");
 
     extern __shared__ __align__(16) double smem[];
     double* const part = smem;                         // [2][S][T][4][64]  partial G
@@ -148,20 +145,18 @@ mfma_sweep_kernel(const MfmaSweepParams P)
     const int k0 = blockIdx.x * 16 * T;
     const int row0 = s * 16 * KW4;
     const size_t pd = (size_t)P.p * d;
-    const StepPtrM steps = (StepPtrM)(unsigned long long)P.steps;
+    typedef const int __attribute__((address_space(4))) * JPtr;
+    const JPtr jidx = (JPtr)(unsigned long long)P.jidx;
 
-    // chain role of this lane: response k0 + 16 q + r (q < T)
+    // chain role of this lane: response k0 + 16 q + r (q < T); every wave runs the whole
+    // chain, wave s stores the results of the steps t = s (mod S)
     const int qc = (q < T) ? q : 0;
     const int kc = k0 + 16 * qc + r;
     const bool cvalid = (q < T) && (kc < d);
     const int kcs = cvalid ? kc : 0;
-    // every wave runs the whole chain; wave s writes the results of the steps t = s (mod S)
-    const bool writer = cvalid;
 
-    // ---- residual into registers (B-operand order) ---------------------------------
-    constexpr int TA = (T < 2) ? T : 2;   // tiles held as MFMA accumulators
-    d4 rv[TA][KW4];
-    double rw[(T > 2) ? KW : 1];          // third tile, plain registers
+    // ---- residual into registers: B operand of the dot MFMAs, C/D of the update MFMAs --
+    d4 rv[T][KW4];
 #pragma unroll
     for (int tau = 0; tau < T; ++tau) {
         const int k = k0 + 16 * tau + r;
@@ -169,11 +164,7 @@ mfma_sweep_kernel(const MfmaSweepParams P)
 #pragma unroll
         for (int g = 0; g < KW; ++g) {
             const int row = row0 + 4 * g + q;
-            const double v = (k < d && row < n) ? Rk[row] : 0.0;
-            if (tau < 2)
-                rv[tau < 2 ? tau : 0][g >> 2][g & 3] = v;
-            else
-                rw[(T > 2) ? g : 0] = v;
+            rv[tau][g >> 2][g & 3] = (k < d && row < n) ? Rk[row] : 0.0;
         }
     }
 
@@ -187,17 +178,19 @@ mfma_sweep_kernel(const MfmaSweepParams P)
     const double cfac = P.cfac;
     double acc_g = 0.0, acc_m2 = 0.0, acc_b2 = 0.0;
 
-    // This wave's X operands form ONE stream in consumption order: 2 KW operands of 64
-    // doubles per block, then a jump over the other waves' share.  A single running
-    // pointer keeps the address arithmetic out of the SGPR file.
+    // This wave's X operands form ONE stream in consumption order (KW dot operands, then
+    // the KW update operands k-slice by k-slice), two operands per 16-byte load.
     const double2* xp = reinterpret_cast<const double2*>(P.XB) + ((size_t)s * KW) * 64 + lane;
-    constexpr size_t blk_skip = (size_t)(S - 1) * KW * 64;  // in operand pairs (double2)
+    constexpr size_t blk_skip = (size_t)(S - 1) * KW * 64;  // other waves' share, in pairs
 
     // ---- block 0: beta_old, Gram and step scalars straight to LDS (parity 0) ---------
+    {
+        int j0[NBW];
 #pragma unroll
-    for (int u = 0; u < NBW; ++u) {
-        const int t = s + u * S;
-        bol[t * 64 + lane] = P.state[2 * pd + (size_t)steps[t].j * d + kcs];
+        for (int u = 0; u < NBW; ++u) j0[u] = jidx[s + u * S];
+#pragma unroll
+        for (int u = 0; u < NBW; ++u)
+            bol[(s + u * S) * 64 + lane] = P.state[2 * pd + (size_t)j0[u] * d + kcs];
     }
     if (tid < 256) gram[tid] = P.gram[tid];
     if (tid < 16) {
@@ -205,7 +198,6 @@ mfma_sweep_kernel(const MfmaSweepParams P)
         scl[2 * tid + 1] = P.steps[tid].xtx;
     }
 
-    // X ring: first operands of block 0's dot phase
     double2 ring[NR2];
 #pragma unroll
     for (int i = 0; i < NR2; ++i) {
@@ -222,22 +214,21 @@ mfma_sweep_kernel(const MfmaSweepParams P)
         const int par = b & 1;
         const bool more = (b + 1 < P.nblk);
 
-        // prefetch for block b + 1: beta_old (this wave's share), Gram matrix, step scalars
-        double bo_nx[NBW];
-        double gr_nx = 0.0, lod_nx = 0.0, xtx_nx = 0.0;
+        // prefetch for block b + 1 (rows past the last block exist: pack pads jidx / steps)
+        int jn[NBW];
 #pragma unroll
-        for (int u = 0; u < NBW; ++u) {
-            const int t = s + u * S;
-            bo_nx[u] = 0.0;
-            if (more) bo_nx[u] = P.state[2 * pd + (size_t)steps[16 * (b + 1) + t].j * d + kcs];
-        }
-        if (tid < 256 && more) gr_nx = P.gram[(size_t)(b + 1) * 256 + tid];
-        if (tid < 16 && more) {
+        for (int u = 0; u < NBW; ++u) jn[u] = jidx[16 * (b + 1) + s + u * S];
+        double bo_nx[NBW];
+#pragma unroll
+        for (int u = 0; u < NBW; ++u) bo_nx[u] = P.state[2 * pd + (size_t)jn[u] * d + kcs];
+        const double gr_nx = (tid < 256) ? P.gram[(size_t)(b + 1) * 256 + tid] : 0.0;
+        double lod_nx = 0.0, xtx_nx = 0.0;
+        if (tid < 16) {
             lod_nx = P.steps[16 * (b + 1) + tid].lod;
             xtx_nx = P.steps[16 * (b + 1) + tid].xtx;
         }
-
         MSTAMP(6);  // issue of next block's operand loads
+
         // ---- (1) G partial = X_J' R over this wave's rows ---------------------------
         d4 acc[T];
 #pragma unroll
@@ -250,14 +241,12 @@ mfma_sweep_kernel(const MfmaSweepParams P)
                 xp += 64;
             }
 #pragma unroll
-            for (int tau = 0; tau < T; ++tau) {
-                const double bv = (tau < 2) ? rv[tau < 2 ? tau : 0][g >> 2][g & 3]
-                                            : rw[(T > 2) ? g : 0];
-                acc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[tau], 0, 0, 0);
-            }
+            for (int tau = 0; tau < T; ++tau)
+                acc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rv[tau][g >> 2][g & 3], acc[tau],
+                                                                0, 0, 0);
         }
+        MSTAMP(0);  // dot MFMAs
 
-        MSTAMP(0);  // prefetch issue + dot MFMAs
         // ---- (2) exchange partial G; one barrier per block ----------------------------
         {
             double* pb = part + ((par * S + s) * T) * 256 + lane;
@@ -271,26 +260,26 @@ mfma_sweep_kernel(const MfmaSweepParams P)
         __syncthreads();
         MSTAMP(2);  // barrier
         // next block's beta_old / Gram / scalars: every wave is past its reads of that parity
-        if (more) {
 #pragma unroll
-            for (int u = 0; u < NBW; ++u) bol[((par ^ 1) * 16 + s + u * S) * 64 + lane] = bo_nx[u];
-            if (tid < 256) gram[(par ^ 1) * 256 + tid] = gr_nx;
-            if (tid < 16) {
-                scl[(par ^ 1) * 32 + 2 * tid] = lod_nx;
-                scl[(par ^ 1) * 32 + 2 * tid + 1] = xtx_nx;
-            }
+        for (int u = 0; u < NBW; ++u) bol[((par ^ 1) * 16 + s + u * S) * 64 + lane] = bo_nx[u];
+        if (tid < 256) gram[(par ^ 1) * 256 + tid] = gr_nx;
+        if (tid < 16) {
+            scl[(par ^ 1) * 32 + 2 * tid] = lod_nx;
+            scl[(par ^ 1) * 32 + 2 * tid + 1] = xtx_nx;
         }
-
-        // ---- (3) the 16 sequential updates of the block, one response per lane --------
-        // Software pipelined by hand: the operands of step t + 1 (beta_old, lod, xtx, Gram
-        // column, covariate index) are requested at the top of step t, so their LDS / scalar
-        // cache latency hides behind the exp / division chain of step t.  The scheduling
-        // barrier at the end of each step keeps later steps' loads from being hoisted
-        // further (register pressure).
         MSTAMP(3);  // next block's operands to LDS
+
+        // ---- (3) the 16 sequential updates of the block, one response per lane, with the
+        //          rank-16 update of the residual riding in their shadow ------------------
+        // The operands of step t + 1 (beta_old, lod, xtx, partial G) are requested at the top
+        // of step t so that their LDS latency hides behind the exp / division chain.
+        // Once steps 4 kk .. 4 kk + 3 are done, the deltas of k-slice kk are known and its
+        // KW4 * T update MFMAs are issued between the instructions of steps 4 kk + 4 ..
+        // 4 kk + 7 (different pipe, independent registers); only the last k-slice runs
+        // after the chain.  The scheduling barrier at the end of each step bounds how far
+        // loads are hoisted (register pressure).
         __builtin_amdgcn_sched_barrier(0);
-        // G_t arrives as S partial sums in LDS; corr[t] collects sum_{s<t} A_ts delta_s
-        double corr[kBlk];
+        double corr[kBlk];  // sum_{s<t} A_ts delta_s
 #pragma unroll
         for (int t = 0; t < kBlk; ++t) corr[t] = 0.0;
         const double* pr = part + ((par * S) * T + qc) * 256 + r;
@@ -299,37 +288,45 @@ mfma_sweep_kernel(const MfmaSweepParams P)
         const double* bo_l = bol + (par * 16) * 64 + lane;
         double bo_c = bo_l[0];
         double2 sc_c = *reinterpret_cast<const double2*>(sc_l);
-        int j_c = steps[16 * b].j;
         double gp_c[S];
 #pragma unroll
         for (int ss = 0; ss < S; ++ss) gp_c[ss] = pr[ss * T * 256];
-        __builtin_amdgcn_sched_barrier(0);
+        int jc[kBlk];
 #pragma unroll
-        for (int t = 0; t < kBlk; ++t) {
-            const int i = 16 * b + t;
-            const bool act = i < P.nsteps;
+        for (int t = 0; t < kBlk; ++t) jc[t] = jidx[16 * b + t];
+        double bop[T];
+        __builtin_amdgcn_sched_barrier(0);
+        sfor<kBlk>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const bool act = 16 * b + t < P.nsteps;
             // requests for step t + 1 and for the end of this step
             double bo_n = 0.0;
             double2 sc_n = make_double2(0.0, 0.0);
-            int j_n = 0;
             double gp_n[S];
-#pragma unroll
-            for (int ss = 0; ss < S; ++ss) gp_n[ss] = 0.0;
-            if (t + 1 < kBlk) {
+            sfor<S>([&](auto sc) { gp_n[decltype(sc)::value] = 0.0; });
+            if constexpr (t + 1 < kBlk) {
                 bo_n = bo_l[(t + 1) * 64];
                 sc_n = *reinterpret_cast<const double2*>(sc_l + 2 * (t + 1));
-                j_n = steps[i + 1].j;
-#pragma unroll
-                for (int ss = 0; ss < S; ++ss)
+                sfor<S>([&](auto sc) {
+                    constexpr int ss = decltype(sc)::value;
                     gp_n[ss] = pr[ss * T * 256 + ((t + 1) >> 2) * 64 + 16 * ((t + 1) & 3)];
+                });
             }
             double gcol[kBlk];
-#pragma unroll
-            for (int t2 = t + 1; t2 < kBlk; ++t2) gcol[t2] = gm_l[t2 * 16 + t];
+            sfor<kBlk - 1 - t>([&](auto c2) {
+                constexpr int t2 = t + 1 + decltype(c2)::value;
+                gcol[t2] = gm_l[t2 * 16 + t];
+            });
+            // B operands of the k-slice completed four steps ago
+            if constexpr (t >= 4 && (t & 3) == 0) {
+                sfor<T>([&](auto tc2) {
+                    constexpr int tau = decltype(tc2)::value;
+                    bop[tau] = dl[(4 * (t / 4 - 1) + q) * 64 + 16 * tau + r];
+                });
+            }
 
             double u = gp_c[0];
-#pragma unroll
-            for (int ss = 1; ss < S; ++ss) u += gp_c[ss];
+            sfor<S - 1>([&](auto sc) { u += gp_c[decltype(sc)::value + 1]; });
             u += corr[t];
             const double dot = fma(sc_c.y, bo_c, u);
             const double m = c_scale * dot;                              // coreLoop.cpp:42-43
@@ -338,11 +335,13 @@ mfma_sweep_kernel(const MfmaSweepParams P)
             const double gmv = div_1to2((a >= 0.0) ? e : 1.0, 1.0 + e);
             const double bn = m * gmv;                                   // :48
             const double delta = (act && cvalid) ? (bo_c - bn) : 0.0;
-#pragma unroll
-            for (int t2 = t + 1; t2 < kBlk; ++t2) corr[t2] = fma(gcol[t2], delta, corr[t2]);
+            sfor<kBlk - 1 - t>([&](auto c2) {
+                constexpr int t2 = t + 1 + decltype(c2)::value;
+                corr[t2] = fma(gcol[t2], delta, corr[t2]);
+            });
             dl[t * 64 + lane] = delta;
-            if (act && writer && (t % S) == s) {
-                double* o = P.state + (size_t)j_c * d + kc;
+            if (act && cvalid && (t % S) == s) {
+                double* o = P.state + (size_t)jc[t] * d + kc;
                 o[0] = gmv;
                 o[pd] = m;
                 o[2 * pd] = bn;
@@ -350,47 +349,28 @@ mfma_sweep_kernel(const MfmaSweepParams P)
                 acc_m2 = fma(gmv, fma(m, m, c_s2), acc_m2);
                 acc_b2 = fma(bn, bn, acc_b2);
             }
+            if constexpr (t >= 4) {
+                // row tiles of k-slice kk handled in this step: i with 4 i / KW4 == t & 3
+                constexpr int kk = t / 4 - 1;
+                sfor<KW4>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr ((4 * i) / KW4 == (t & 3)) LOCUS_UPD_SLOT(kk, i);
+                });
+            }
             bo_c = bo_n;
             sc_c = sc_n;
-            j_c = j_n;
-#pragma unroll
-            for (int ss = 0; ss < S; ++ss) gp_c[ss] = gp_n[ss];
+            sfor<S>([&](auto sc) { gp_c[decltype(sc)::value] = gp_n[decltype(sc)::value]; });
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
+        MSTAMP(4);  // chain (+ 3/4 of the update MFMAs)
 
-        MSTAMP(4);  // chain
-        // ---- (4) R += X_J delta on the matrix cores ------------------------------------
-        double bop[T][4];
+        // ---- (4) last k-slice of R += X_J delta ------------------------------------------
 #pragma unroll
-        for (int tau = 0; tau < T; ++tau) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) bop[tau][kk] = dl[(4 * kk + q) * 64 + 16 * tau + r];
-        }
-        d4 upd = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int g = 0; g < KW; ++g) {  // g = 4 * tile + kk
-            const int slot = ((g + KW) % NR) >> 1;
-            const double a = (g & 1) ? ring[slot].y : ring[slot].x;
-            if (g & 1) {
-                if (g + NR - 1 == KW) xp += blk_skip;  // the stream continues in the next block
-                if (g + NR - 1 < KW || more) {
-                    ring[slot] = *xp;
-                    xp += 64;
-                }
-            }
-#pragma unroll
-            for (int tau = 0; tau < TA; ++tau)
-                rv[tau][g >> 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[tau][g & 3],
-                                                                       rv[tau][g >> 2], 0, 0, 0);
-            if constexpr (T > 2) {
-                if ((g & 3) == 0) upd = d4{0.0, 0.0, 0.0, 0.0};
-                upd = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[2][g & 3], upd, 0, 0, 0);
-                if ((g & 3) == 3) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rw[g - 3 + e] += upd[e];
-                }
-            }
-        }
+        for (int tau = 0; tau < T; ++tau) bop[tau] = dl[(12 + q) * 64 + 16 * tau + r];
+        sfor<KW4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            LOCUS_UPD_SLOT(3, i);
+        });
         MSTAMP(5);  // update MFMAs
     }
 
@@ -408,7 +388,7 @@ mfma_sweep_kernel(const MfmaSweepParams P)
 #pragma unroll
         for (int g = 0; g < KW; ++g) {
             const int row = row0 + 4 * g + q;
-            const double v = (tau < 2) ? rv[tau < 2 ? tau : 0][g >> 2][g & 3] : rw[(T > 2) ? g : 0];
+            const double v = rv[tau][g >> 2][g & 3];
             if (k < d && row < n) Rk[row] = v;
             a0 = fma(v, v, a0);
         }
@@ -416,16 +396,16 @@ mfma_sweep_kernel(const MfmaSweepParams P)
     }
     if (P.st != nullptr) {
         __syncthreads();  // all waves are done with `part`
-        // part[s][tau][lane] <- partial sum of squares; lane (q, r) then adds S * 4 values
+        // part[s][tau][lane] <- partial sum of squares; the column statistics were accumulated
+        // by the wave that stored the step
 #pragma unroll
         for (int tau = 0; tau < T; ++tau) part[(s * T + tau) * 64 + lane] = ss2[tau];
-        // the column statistics were accumulated by the wave that stored the step
         double* sacc = part + S * T * 64;  // [S][3][64]
         sacc[(s * 3 + 0) * 64 + lane] = acc_g;
         sacc[(s * 3 + 1) * 64 + lane] = acc_m2;
         sacc[(s * 3 + 2) * 64 + lane] = acc_b2;
         __syncthreads();
-        if (writer && s == 0) {
+        if (cvalid && s == 0) {
             double tot = 0.0, sg = 0.0, sm = 0.0, sb = 0.0;
 #pragma unroll
             for (int ss = 0; ss < S; ++ss) {
@@ -442,5 +422,6 @@ mfma_sweep_kernel(const MfmaSweepParams P)
         }
     }
 }
+#undef LOCUS_UPD_SLOT
 
 }  // namespace locus

@@ -23,6 +23,7 @@
 //    reductions update_vb.R:220,229-237 and elbo.R need.
 #pragma once
 #include "common.h"
+#include "fastmath.h"
 
 namespace locus {
 
@@ -397,8 +398,8 @@ sweep_kernel(const SweepParams P)
                 a = P.cfac * ((st_lod - m * m * k01.y) + k23.x);      // coreLoop.cpp:45-46
             }
             // exp(-log(1 + exp(a))) = 1 / (1 + exp(a)), evaluated without overflow
-            const double e = exp(-fabs(a));
-            const double gm = ((a >= 0.0) ? e : 1.0) / (1.0 + e);
+            const double e = exp_nonpos(-fabs(a));
+            const double gm = div_1to2((a >= 0.0) ? e : 1.0, 1.0 + e);
             const double bn = m * gm;                            // coreLoop.cpp:48
             const double delta = (act && cvalid) ? (bo - bn) : 0.0;
             LOCUS_STAMP(3);  // element-wise update

@@ -82,8 +82,8 @@ def test_two_sweeps_in_a_row_deterministic(hip):
 
 # matrix-core kernel, explicit geometries -1,T,S,KW4 (T tiles of 16 responses per workgroup,
 # S waves, KW4 16-row tiles per wave): ragged rows / responses / last block of the sweep
-MFMA_GEOMS = ["-1,1,4,1", "-1,2,4,1", "-1,3,4,2", "-1,1,8,2", "-1,2,4,4", "-1,3,4,4", "-1,1,4,8",
-              "-1,2,8,4", "-1,1,4,16", "-1,3,4,16", "-1,2,4,16", "-1,2,4,8", "-1,3,4,8"]
+MFMA_GEOMS = ["-1,1,4,1", "-1,2,4,1", "-1,2,4,2", "-1,1,8,2", "-1,2,4,4", "-1,1,4,4", "-1,1,4,8",
+              "-1,2,8,4", "-1,1,4,16", "-1,2,4,16", "-1,2,4,8", "-1,1,8,16", "-1,2,8,8"]
 
 
 @pytest.mark.parametrize("geom", MFMA_GEOMS)
