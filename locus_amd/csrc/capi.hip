@@ -136,8 +136,9 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
     SweepConfig cfg;
     if (a->cfg[0] != 0) {
         cfg = SweepConfig{a->cfg[0], a->cfg[1], a->cfg[2], a->cfg[3]};
-        LOCUS_REQUIRE(cfg.C >= 1 && cfg.S >= 1 && cfg.G >= 1 &&
-                          (cfg.NPL < 0 || (int64_t)cfg.NPL * cfg.S * 64 >= a->n),
+        LOCUS_REQUIRE(cfg.NPL < 0 ? (cfg.C >= 0 && cfg.G >= 0)
+                                  : (cfg.C >= 1 && cfg.S >= 1 && cfg.G >= 1 &&
+                                     (int64_t)cfg.NPL * cfg.S * 64 >= a->n),
                       "sweep: bad explicit geometry");
     } else {
         rc = choose_sweep_config((int)a->n, (int)a->d, logit != 0, &cfg);

@@ -81,9 +81,11 @@ struct SweepConfig {
 };
 
 // NPL == -1 selects the matrix-core kernel (mfma_sweep_kernel.h); then C = tiles of 16 responses
-// per workgroup (1..3), S = waves per workgroup (4, 8, 16), G = 16-row tiles per wave.
+// per workgroup (1, 2; 0 = planned from d), S is ignored, G = 16-row tiles per matrix wave (0 =
+// smallest instantiated value that covers n).
 int choose_sweep_config(int n, int d, bool logit, SweepConfig* cfg);
 size_t mfma_workspace_bytes(int64_t n, int64_t p);
+bool mfma_sweep_covers(int n);
 int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
                    hipStream_t st);
 int launch_sweep(const SweepParams& prm, const SweepConfig& cfg, bool logit, hipStream_t stream);

@@ -11,132 +11,213 @@ int launch_mfma_sweep_t1(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStr
 int launch_mfma_sweep_t2(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
 
 // ---------------------------------------------------------------------------
-// One workgroup per block of 16 consecutive sweep steps: gathers the 16 columns of the packed
-// X (128 rows at a time through LDS) and writes them in the two MFMA operand orders
-//   dot operand g:        l -> X[4 g + (l >> 4)][j_{l & 15}]            (A of G = X_J' R)
-//   update operand (t,kk): l -> X[16 t + (l & 15)][j_{4 kk + (l >> 4)}]  (A of R += X_J delta)
-// stored as XB[b][wave][KW][64][2] (KW = k-steps of 4 rows per wave; consecutive operands paired
-// per lane): the order in which wave `wave` consumes them.  Also the block's Gram matrix gram[b][t][s] = X_{j_t}' X_{j_s}.  Rows >= n are zero.
-// Bandwidth-bound: reads p*ld, writes 2*p*rows_pad doubles per sweep.
+// One workgroup per iteration slot b = 0 .. nblk + 1 of the sweep.  For b < nblk it gathers the
+// 16 columns of block b (128 rows at a time through LDS) and writes them in the two MFMA operand
+// orders
+//   dot operand (i, g):    l -> X[16 i + 4 g + (l >> 4)][j_{l & 15}]        (A of G = X_b' R)
+//   update operand (i, c): l -> X[16 i + (l & 15)][j_{4 c + (l >> 4)}]      (A of R += X_b delta)
+// into the per-wave streams XS[wave][it][8 KT][64] (mfma_sweep_kernel.h): the dot operands of
+// block b belong to iteration it = b, its update operands to iteration it = b + 2.  Parts that no
+// block fills (update of it = 0, 1; dot of it >= nblk) are zeroed.  Also: the block's strictly
+// lower Gram matrix by columns, cg[b][t][t'] = X_t' . X_t (t' > t), and the cross-block Gram matrix
+// X_{b+1}' X_b in A-operand order at axo[b + 2].  Rows >= n are zero (Xp is zero padded to ld).
+// Bandwidth-bound: reads 2 p ld, writes 2 p rows_pad doubles per sweep.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ steps,
-                   double* __restrict__ XB, double* __restrict__ gram, int* __restrict__ jidx,
-                   int ld, int rows_pad, int KW)
+                   double* __restrict__ XS, double* __restrict__ cg, double* __restrict__ axo,
+                   int* __restrict__ jidx, int ld, int KT, int nblk, int MW)
 {
     __shared__ double xt[16][130];
-    __shared__ int js[16];
+    __shared__ double xn[16][130];
+    __shared__ int js[16], jn[16];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int nit = nblk + 2;
+    const bool has = b < nblk, has_next = b + 1 < nblk;
     if (tid < 16) {
-        js[tid] = steps[16 * b + tid].j;
+        js[tid] = has ? steps[16 * b + tid].j : 0;
+        jn[tid] = has_next ? steps[16 * (b + 1) + tid].j : 0;
         jidx[16 * b + tid] = js[tid];
-        if (b == gridDim.x - 1) jidx[16 * (b + 1) + tid] = 0;  // readable tail (prefetch)
     }
-    const size_t blk = (size_t)rows_pad * 32;  // doubles per block (both operand sets)
+    const int rows_pad = MW * 16 * KT;
+    const int NOP = 8 * KT;
     const int gt = tid >> 4, gs = tid & 15;
-    double gacc = 0.0;
+    double gacc = 0.0, xacc = 0.0;
     for (int c0 = 0; c0 < rows_pad; c0 += 128) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i;
             const int col = e >> 7, rr = e & 127, row = c0 + rr;
-            xt[col][rr] = (row < ld) ? Xp[(size_t)js[col] * ld + row] : 0.0;
+            xt[col][rr] = (has && row < ld) ? Xp[(size_t)js[col] * ld + row] : 0.0;
+            xn[col][rr] = (has_next && row < ld) ? Xp[(size_t)jn[col] * ld + row] : 0.0;
         }
         __syncthreads();
-        const int rows_here = min(128, rows_pad - c0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int o = tid + 256 * i;
             const int ln = o & 63;
-            const int gl = o >> 6;  // k-step inside the chunk
-            if (4 * gl < rows_here) {
-                // global k-step -> (wave, k-step in wave); update operands use the same index
-                // (4 * tile + kk) and sit KW operands after the wave's dot operands
-                const int gg = (c0 >> 2) + gl;
-                const int w = gg / KW, gi = gg - w * KW;
-                // operand o of the wave's stream -> pair o >> 1, element o & 1 of lane ln
-                double* wb = XB + (size_t)b * blk + (size_t)w * KW * 128 + ln * 2;
-                wb[(size_t)(gi >> 1) * 128 + (gi & 1)] = xt[ln & 15][4 * gl + (ln >> 4)];
-                const int tl = gl >> 2, kk = gl & 3;  // 16-row tile inside the chunk, k-slice
-                const int ou = KW + kk * (KW >> 2) + (gi >> 2);  // k-slice major, row tile minor
-                wb[(size_t)(ou >> 1) * 128 + (ou & 1)] = xt[4 * kk + (ln >> 4)][16 * tl + (ln & 15)];
+            const int sub = (o >> 6) & 3;  // k-step (dot) or covariate slice (update)
+            const int gl = o >> 8;         // 16-row tile inside the chunk
+            const int gtile = (c0 >> 4) + gl;
+            if (gtile < MW * KT) {
+                const int wv = gtile / KT, ti = gtile - wv * KT;
+                const int oi = op_index(ti, sub, KT);
+                const double vd = xt[ln & 15][16 * gl + 4 * sub + (ln >> 4)];
+                const double vu = xt[4 * sub + (ln >> 4)][16 * gl + (ln & 15)];
+                // dot part of iteration b: operands 4 KT .. 8 KT - 1
+                {
+                    const int ot = 4 * KT + oi;
+                    XS[(((size_t)wv * nit + b) * NOP + (ot & ~1)) * 64 + ln * 2 + (ot & 1)] = vd;
+                }
+                // update part of iteration b + 2: operands 0 .. 4 KT - 1
+                if (has) {
+                    XS[(((size_t)wv * nit + b + 2) * NOP + (oi & ~1)) * 64 + ln * 2 + (oi & 1)] = vu;
+                }
+                if (b < 2) {  // nobody fills the update part of iterations 0 and 1
+                    XS[(((size_t)wv * nit + b) * NOP + (oi & ~1)) * 64 + ln * 2 + (oi & 1)] = 0.0;
+                }
             }
         }
-        for (int rr = 0; rr < 128; ++rr) gacc = fma(xt[gt][rr], xt[gs][rr], gacc);
+        for (int rr = 0; rr < 128; ++rr) {
+            gacc = fma(xt[gt][rr], xt[gs][rr], gacc);
+            xacc = fma(xn[gt][rr], xt[gs][rr], xacc);
+        }
     }
-    gram[(size_t)b * 256 + tid] = gacc;
+    // column gs of the strictly lower triangle: cg[b][t = gs][t' = gt]
+    cg[(size_t)b * 256 + gs * 16 + gt] = (gt > gs) ? gacc : 0.0;
+    // cross Gram (X_{b+1}' X_b)[t' = gt][t = gs] as A operand c = gs >> 2, lane (gs & 3) * 16 + gt,
+    // consumed in iteration b + 2
+    if (b + 2 < nit) axo[((size_t)(b + 2) * 4 + (gs >> 2)) * 64 + (gs & 3) * 16 + gt] = xacc;
+    if (b < 2) axo[((size_t)b * 4 + (gs >> 2)) * 64 + (gs & 3) * 16 + gt] = 0.0;
 }
 
-size_t mfma_rows_pad_max(int64_t n)
+// row tiles of 16 per matrix wave for n rows: the instantiated KT values
+int mfma_kt_for(int64_t n, int T)
 {
-    size_t r = 64;
-    while ((int64_t)r < n) r <<= 1;
-    return r;
+    static const int kts2[] = {2, 4, 6, 9, 0};         // instantiated for T = 2 (7 matrix waves)
+    static const int kts1[] = {2, 4, 6, 8, 11, 21, 0};  // T = 1 (6 matrix waves)
+    for (const int* kt = (T == 2) ? kts2 : kts1; *kt; ++kt)
+        if ((int64_t)mfma_waves(T) * 16 * *kt >= n) return *kt;
+    return 0;
 }
 
 // bytes of the block-packed operands for a sweep over p covariates of n rows
 size_t mfma_workspace_bytes(int64_t n, int64_t p)
 {
-    const size_t nblk = ((size_t)p + 15) / 16;
-    const size_t rp = mfma_rows_pad_max(n);
-    return sizeof(double) * (2 * nblk * rp * 16 + (nblk + 1) * 256) + sizeof(int) * 16 * (nblk + 1) +
-           1024;
+    const size_t nit = ((size_t)p + 15) / 16 + 2;
+    const int kt1 = mfma_kt_for(n, 1), kt2 = mfma_kt_for(n, 2);
+    if (kt1 == 0) return 1024;  // the matrix-core sweep does not cover this n
+    const size_t rows_pad = std::max((size_t)mfma_waves(1) * 16 * kt1, (size_t)mfma_waves(2) * 16 * kt2);
+    return sizeof(double) * (nit * rows_pad * 32 + 2 * nit * 256) + sizeof(int) * 16 * nit +
+           32 * 1024;
 }
 
-size_t mfma_lds_bytes(int T, int S)
+size_t mfma_lds_bytes(int T)
 {
-    return sizeof(double) * (2 * (size_t)S * T * 256 + 2 * 16 * 64 + 2 * 256 + 2 * 32 + 16 * 64);
+    return sizeof(double) * (2 * (size_t)(mfma_waves(T) + 1) * T * 256 + 2 * 16 * 64 + 2 * 16 * 64 + 2 * 256 + 2 * 64 + 8);
 }
 
-// cfg: C = T (tiles per workgroup), S = waves per workgroup, G = KW4 (16-row tiles per wave)
-int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
-                   hipStream_t st)
+static int device_cus()
 {
-    const int T = cfg.C, S = cfg.S, KW4 = cfg.G;
-    if (T < 1 || T > 2 || (S != 4 && S != 8) ||
-        (KW4 != 1 && KW4 != 2 && KW4 != 4 && KW4 != 8 && KW4 != 16)) {
-        set_error("mfma sweep: bad geometry (T in 1..2, S in {4,8}, KW4 in {1,2,4,8,16})");
-        return LOCUS_HIP_EINVAL;
+    static int cus = 0;  // same for every device of a node
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
     }
-    const int rows_pad = 16 * KW4 * S;
-    if (rows_pad < prm.n) {
+    return cus;
+}
+
+// true when the matrix-core sweep covers n rows (identity family only)
+bool mfma_sweep_covers(int n) { return mfma_kt_for(n, 1) > 0; }
+
+static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, int k_end, bool pack,
+                           void* xb_ws, size_t xb_bytes, hipStream_t st)
+{
+    const int MW = mfma_waves(T);
+    const int rows_pad = MW * 16 * KT;
+    if (KT <= 0 || rows_pad < prm.n) {
         set_error("mfma sweep: geometry does not cover n rows");
         return LOCUS_HIP_EINVAL;
     }
     const int nblk = (prm.nsteps + 15) / 16;
-    const size_t xb = (size_t)nblk * rows_pad * 32;  // doubles of the packed operand stream
-    if (sizeof(double) * (xb + ((size_t)nblk + 1) * 256) + sizeof(int) * 16 * ((size_t)nblk + 1) +
-            512 > xb_bytes) {
+    const size_t nit = (size_t)nblk + 2;
+    const size_t xs = nit * rows_pad * 32;  // doubles of the packed operand streams
+    if (sizeof(double) * (xs + 2 * nit * 256) + sizeof(int) * 16 * nit + 32 * 1024 > xb_bytes) {
         set_error("mfma sweep: workspace too small");
         return LOCUS_HIP_EINVAL;
     }
     char* base = static_cast<char*>(xb_ws);
     base += (256 - ((uintptr_t)base & 255)) & 255;
-    double* XB = reinterpret_cast<double*>(base);
-    double* gram = XB + xb;                                  // [nblk + 1][256] (tail: prefetch)
-    int* jidx = reinterpret_cast<int*>(gram + ((size_t)nblk + 1) * 256);
+    double* XS = reinterpret_cast<double*>(base);
+    double* cgp = XS + xs + 2048;  // 16 KB of slack: the operand ring reads ahead of the stream
+    double* axo = cgp + nit * 256;
+    int* jidx = reinterpret_cast<int*>(axo + nit * 256);
 
-    hipLaunchKernelGGL(pack_blocks_kernel, dim3(nblk), dim3(256), 0, st, prm.Xp, prm.steps, XB, gram,
-                       jidx, prm.ld, rows_pad, 4 * KW4);
-    LOCUS_HIP_CHECK(hipGetLastError());
+    if (pack) {
+        hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)nit), dim3(256), 0, st, prm.Xp,
+                           prm.steps, XS, cgp, axo, jidx, prm.ld, KT, nblk, MW);
+        LOCUS_HIP_CHECK(hipGetLastError());
+    }
 
     MfmaSweepParams mp;
     mp.n = prm.n; mp.p = prm.p; mp.d = prm.d;
-    mp.nblk = nblk; mp.nsteps = prm.nsteps; mp.rows_pad = rows_pad;
+    mp.k_begin = k_begin; mp.k_end = k_end;
+    mp.nblk = nblk; mp.nsteps = prm.nsteps;
     mp.steps = prm.steps; mp.err = prm.err;
-    mp.XB = XB; mp.gram = gram; mp.jidx = jidx;
+    mp.XS = XS; mp.cg = cgp; mp.axo = axo; mp.jidx = jidx;
     mp.scale = prm.scale; mp.hinv = prm.hinv; mp.cst = prm.cst; mp.s2k = prm.s2k;
     mp.cfac = prm.cfac;
     mp.R = prm.R; mp.state = prm.state; mp.st = prm.st;
 
-    const long n_wg = ((long)prm.d + 16L * T - 1) / (16L * T);
-    dim3 grid((unsigned)n_wg), block((unsigned)(64 * S));
-    const size_t lds = mfma_lds_bytes(T, S);
+    const long n_wg = ((long)(k_end - k_begin) + 16L * T - 1) / (16L * T);
+    dim3 grid((unsigned)n_wg), block((unsigned)(64 * (MW + 1)));
+    const size_t lds = mfma_lds_bytes(T);
     switch (T) {
-        case 1: return launch_mfma_sweep_t1(mp, KW4, grid, block, lds, st);
-        default: return launch_mfma_sweep_t2(mp, KW4, grid, block, lds, st);
+        case 1: return launch_mfma_sweep_t1(mp, KT, grid, block, lds, st);
+        default: return launch_mfma_sweep_t2(mp, KT, grid, block, lds, st);
     }
+}
+
+// cfg: C = T (tiles of 16 responses per workgroup; 0 = plan by d), G = KT (16-row tiles per matrix
+// wave, 0 = smallest instantiated value that covers n).
+// Planned mode: a workgroup holds its responses in the registers of a whole CU, so one launch
+// takes at most 32 (T = 2) or 16 (T = 1) responses per CU.  Measured at n = 1000 (MI355X): a T = 2
+// launch costs ~1.4x a T = 1 launch, so responses go to T = 2 launches while more than one T = 1
+// launch's worth is left, and the remainder to T = 1.
+int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
+                   hipStream_t st)
+{
+    if (cfg.C < 0 || cfg.C > 2) {
+        set_error("mfma sweep: bad geometry (T in 0..2)");
+        return LOCUS_HIP_EINVAL;
+    }
+    if (cfg.C != 0) {
+        const int KT = cfg.G > 0 ? cfg.G : mfma_kt_for(prm.n, cfg.C);
+        return pack_and_launch(prm, cfg.C, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
+    }
+    const int kt1 = mfma_kt_for(prm.n, 1), kt2 = mfma_kt_for(prm.n, 2);
+    if (kt1 == 0) {
+        set_error("mfma sweep: n too large for the matrix-core kernel");
+        return LOCUS_HIP_EUNSUPPORTED;
+    }
+    const int cus = device_cus();
+    const int cap1 = 16 * cus, cap2 = 32 * cus;
+    int k = 0, last_T = 0;
+    while (k < prm.d) {
+        const int rem = prm.d - k;
+        const int T = (kt2 > 0 && rem > cap1) ? 2 : 1;
+        const int take = std::min(rem, T == 2 ? cap2 : cap1);
+        const int rc = pack_and_launch(prm, T, T == 2 ? kt2 : kt1, k, k + take, T != last_T, xb_ws,
+                                       xb_bytes, st);
+        if (rc) return rc;
+        last_T = T;
+        k += take;
+    }
+    return 0;
 }
 
 }  // namespace locus

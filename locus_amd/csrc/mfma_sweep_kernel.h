@@ -1,28 +1,31 @@
-// CAVI sweep on the fp64 matrix cores of gfx950 -- blocked coordinate ascent.
+// CAVI sweep on the fp64 matrix cores of gfx950 -- blocked coordinate ascent with look-ahead.
 //
 // Same update as sweep_kernel.h (src/coreLoop.cpp:36-52, coreStructLoop.cpp:34-50,
 // coreZLoop / coreProbitLoop), restated so that the O(n) work per (covariate, response)
-// pair runs as v_mfma_f64_16x16x4_f64 instead of vector FMAs + cross-lane reductions
-// (measured on MI355X: MFMA fp64 sustains 77.6 TFLOP/s, v_fma_f64 about 60).
+// pair runs as v_mfma_f64_16x16x4_f64 and overlaps with the sequential element-wise chain.
 //
-// The sweep order is cut into blocks of B = 16 consecutive covariates j_0..j_15.  With R the
-// residual at the start of a block and d_s = beta_old - beta_new of step s,
-//     X_t' R^(t) = X_t' (R + sum_{s<t} X_s d_s) = G_t + sum_{s<t} A_ts d_s,
-//     G = X_J' R  (16 x responses),     A = X_J' X_J  (16 x 16, the block's Gram matrix),
-// and after the block R += X_J d.  G and the rank-16 update are dense contractions over the
-// n rows (the matrix cores); the 16 sequential element-wise updates of a block touch only
-// O(16) numbers per response and run with one response per lane.  The algebra is the same
-// folding the reference uses in src/coreBatch.cpp:32-33; only the summation order differs.
+// The sweep order is cut into blocks of 16 consecutive covariates.  With R the residual before
+// block b, d_s = beta_old - beta_new of step s and A_b = X_b' X_b (16 x 16),
+//     X_t' R^(t) = G_t + sum_{s<t} A_b[t][s] d_s,      G = X_b' R,      R += X_b d  afterwards
+// (the folding of src/coreBatch.cpp:32-33, re-associated).  Look-ahead: G of block b is formed
+// from the residual that has seen the updates of blocks <= b - 2 only,
+//     G_b = X_b' (R_{b-2} applied) + (X_b' X_{b-1}) d_{b-1},
+// so the dense work of iteration `it` (apply block it-2, project on block it) does not depend on
+// the chain of block it-1 that runs at the same time.
 //
-// Work decomposition: a workgroup of S waves owns 16*T responses (T tiles) for the whole
-// sweep; wave s owns rows [s*16*KW4, (s+1)*16*KW4) of those columns IN REGISTERS, laid out as
-// the B operand of the dot MFMAs == the C/D operand of the update MFMAs:
-//     lane l, tile tau, k-step g (row 4g + (l>>4), response 16 tau + (l&15))  ->  rv[tau][g>>2][g&3].
-// X arrives from global memory already in MFMA operand order (two block-packed copies built
-// once per sweep by pack_blocks_kernel: XBd for G, XBu for the update), one coalesced 512-byte
-// load per MFMA operand, prefetched through a register ring; X never touches LDS.
-// Per block: dot MFMAs -> partial G to LDS -> ONE barrier -> every wave runs the 16-step
-// chain redundantly (lane = response) -> deltas through LDS -> update MFMAs.
+// A workgroup owns 16 T responses for the whole sweep and has two roles:
+//   waves 0..6 (matrix role): wave w keeps rows [16 KT w, 16 KT (w + 1)) of those columns as MFMA
+//       accumulators (C/D layout of R += X_b d == B-operand layout of G = X_b' R) and streams its
+//       X operands from global memory in consumption order (pack_blocks_kernel); never touches
+//       the element-wise math;
+//   wave 7 (chain role): one response per lane; sums the 7 partial G tiles and the cross-block
+//       correction from LDS, runs the 16 sequential updates of the block, writes gam / mu /
+//       beta and the deltas (LDS) that the matrix waves consume one iteration later.
+// The cross-block correction of the NEXT block, (X_{b+1}' X_b) d_b, is formed by one matrix wave
+// (with 7 matrix waves: the one that shares its SIMD with the chain wave only and idles most):
+// it follows the chain's progress word in LDS and issues 4 T MFMAs, one group as soon as each
+// group of four deltas is known.  ONE barrier per iteration publishes deltas, partial G,
+// cross correction, beta_old and step scalars.
 #pragma once
 #include <utility>
 
@@ -48,19 +51,46 @@ __device__ __forceinline__ void sfor(F&& f)
 }
 
 constexpr int kBlk = 16;  // covariates per block (M of the MFMA)
+// Matrix-role waves per workgroup.  Measured on MI355X: an fp64 MFMA stream on the SIMD of the
+// chain wave slows the chain by 1.5-1.9x.  T = 2 is bound by the matrix work, so it spreads it
+// over all four SIMDs (7 matrix waves; the chain wave, id 7, shares SIMD 3 with matrix wave 3).
+// T = 1 is bound by the chain: 6 matrix waves on SIMDs 0..2 and the chain wave (id 3) alone on
+// SIMD 3 (waves of a workgroup go to the SIMDs round-robin).
+__host__ __device__ constexpr int mfma_waves(int T) { return T == 1 ? 6 : 7; }
+
+// Order of the 4 KT operands of one part (update or dot) in a wave's stream: row tiles are
+// interleaved in pairs so that consecutive MFMAs never accumulate into the same registers.
+// o -> (row tile i, sub-step c); c = covariate slice (update) or 4-row k-step (dot).
+__host__ __device__ constexpr int op_tile(int o, int KT)
+{
+    const int ip = o >> 3, rem = o & 7;
+    return (2 * ip + 1 < KT) ? 2 * ip + (rem & 1) : 2 * ip;
+}
+__host__ __device__ constexpr int op_sub(int o, int KT)
+{
+    const int ip = o >> 3, rem = o & 7;
+    return (2 * ip + 1 < KT) ? (rem >> 1) : rem;
+}
+// inverse: (i, c) -> o
+__host__ __device__ constexpr int op_index(int i, int c, int KT)
+{
+    const int ip = i >> 1;
+    return (2 * ip + 1 < KT) ? 8 * ip + 2 * c + (i & 1) : 8 * ip + c;
+}
 
 struct MfmaSweepParams {
     int n, p, d;
+    int k_begin, k_end;  // responses [k_begin, k_end) of the d columns are swept by this launch
     int nblk;            // blocks of 16 steps (last one padded with inactive steps)
     int nsteps;          // active steps
-    int rows_pad;        // 16 * KW4 * S  (>= n)
     const StepRec* steps;  // [16 * nblk + 16]
     const int* err;
-    const double* XB;    // [nblk][S][KW][64][2]: per block and wave, the KW dot operands
-                         // (A of G = X_J' R) then the KW update operands (A of R += X_J delta),
+    const double* XS;    // [MW][nblk + 2][8 KT][64]: per wave and iteration `it`, the 4 KT update
+                         // operands of block it - 2 then the 4 KT dot operands of block it,
                          // consecutive operands paired per lane (one 16-byte load = 2 operands)
-    const double* gram;  // [nblk][16][16]              X_J'X_J
-    const int* jidx;     // [16 * nblk + 16]            covariate index of every step
+    const double* cg;    // [nblk + 2][16][16]: cg[b][t][t'] = X_t' X_t' of block b for t' > t, else 0
+    const double* axo;   // [nblk + 2][4][64]: X_{it-1}' X_{it-2} as the 4 A operands of a 16x16x16 product
+    const int* jidx;     // [16 * (nblk + 2)]  covariate index of every step (tail: 0)
     const double* scale; // per-response constants, as SweepParams
     const double* hinv;
     const double* cst;
@@ -72,14 +102,28 @@ struct MfmaSweepParams {
 };
 
 typedef const StepRec __attribute__((address_space(4))) * StepPtrM;
+typedef const double __attribute__((address_space(4))) * CDblPtr;
+typedef const int __attribute__((address_space(4))) * CIntPtr;
 
-#ifndef LOCUS_RING
-#define LOCUS_RING 8
+// X operand pairs in flight per matrix wave (must divide 4 KT)
+template <int T, int KT>
+constexpr int ring_pairs()
+{
+    // largest divisor of 4 KT within the register budget (T = 2 keeps 16 KT residual registers)
+#if defined(LOCUS_RING_T1) && defined(LOCUS_RING_T2)
+    constexpr int cap = (T == 1) ? LOCUS_RING_T1 : LOCUS_RING_T2;
+#else
+    constexpr int cap = (T == 1) ? 12 : 6;
 #endif
-constexpr int kRing = LOCUS_RING;  // X operands in flight per wave
+    int best = 1;
+    for (int r = 1; r <= cap; ++r)
+        if ((4 * KT) % r == 0) best = r;
+    return best;
+}
 
-// Diagnostic build only (-DLOCUS_STAMPS, `make diag`): per-phase cycle sums of wave 0 of every
-// workgroup.  No stamp executes in the product build.
+// Diagnostic build only (-DLOCUS_STAMPS, `make diag`): per-phase cycle sums of wave 0 (slots
+// 0..4) and of the chain wave (slots 5..7) of every workgroup.  No stamp executes in the
+// product build.
 #ifdef LOCUS_STAMPS
 __device__ unsigned long long g_mfma_stamps[8 * 4096];
 #define MSTAMP(k)                                                                        \
@@ -95,333 +139,380 @@ __device__ unsigned long long g_mfma_stamps[8 * 4096];
 #define MSTAMP(k) do { } while (0)
 #endif
 
-// One update MFMA slot: row tile `i` of k-slice `kk` (covariates 4 kk .. 4 kk + 3 of the block),
-// operand number KW + kk * KW4 + i of the wave's stream for this block.
-#define LOCUS_UPD_SLOT(kk, i)                                                                  \
-    do {                                                                                       \
-        constexpr int o_ = KW + (kk) * KW4 + (i);      /* operand index in the block stream */  \
-        constexpr int sl_ = (o_ % NR) >> 1;                                                    \
-        const double a_ = (o_ & 1) ? ring[sl_].y : ring[sl_].x;                                \
-        if constexpr ((o_ & 1) != 0) {                                                         \
-            if constexpr (o_ + NR - 1 == 2 * KW) xp += blk_skip;                               \
-            if (o_ + NR - 1 < 2 * KW || more) {                                                \
-                ring[sl_] = *xp;                                                               \
-                xp += 64;                                                                      \
-            }                                                                                  \
-        }                                                                                      \
-        sfor<T>([&](auto tc_) {                                                                \
-            constexpr int tau_ = decltype(tc_)::value;                                         \
-            rv[tau_][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bop[tau_], rv[tau_][i], 0,  \
-                                                               0, 0);                          \
-        });                                                                                    \
-    } while (0)
-
-template <int T, int KW4, int S>
-__global__ void __launch_bounds__(64 * S)
+template <int T, int KT>
+__global__ void __launch_bounds__(64 * (mfma_waves(T) + 1))
 mfma_sweep_kernel(const MfmaSweepParams P)
 {
     static_assert(T >= 1 && T <= 2, "1 or 2 response tiles per workgroup");
-    static_assert(S == 4 || S == 8, "4 or 8 waves per workgroup");
-    constexpr int KW = 4 * KW4;          // k-steps (4 rows each) per wave
-    constexpr int NR = (KW < kRing) ? KW : kRing;  // operands in flight (even)
-    constexpr int NR2 = NR / 2;
-    constexpr int NBW = 16 / S;          // beta_old loads per wave and block
-    static_assert((2 * KW) % NR == 0 && NR % 2 == 0, "ring must divide the block stream");
+    constexpr int NOP = 8 * KT;        // X operands per wave and iteration
+    constexpr int NPAIR = NOP / 2;     // 16-byte loads per wave and iteration
+    constexpr int NR2 = ring_pairs<T, KT>();
+    static_assert(NPAIR % NR2 == 0, "ring must divide the iteration stream");
+    constexpr int NACC = (T == 1) ? 2 : 1;  // dot accumulators per response tile
+    constexpr int MW = mfma_waves(T);       // matrix waves
+    constexpr int CW = (MW == 7) ? 7 : 3;   // id of the chain wave
+    constexpr int XW = (MW == 7) ? 3 : 0;   // matrix wave (logical index) forming the cross correction
+    constexpr int NSL = MW + 1;             // partial-G slots: matrix waves + cross correction
+    constexpr int NTHR = 64 * (MW + 1);
 
     extern __shared__ __align__(16) double smem[];
-    double* const part = smem;                         // [2][S][T][4][64]  partial G
-    double* const bol = part + 2 * S * T * 256;        // [2][16][64]       beta_old of the block
-    double* const gram = bol + 2 * 16 * 64;            // [2][256]          X_J'X_J
-    double* const scl = gram + 2 * 256;                // [2][16][2]        lod, xtx of the steps
-    double* const dl = scl + 2 * 32;                   // [16][64]          deltas of the block
+    double* const part = smem;                          // [2][NSL][T][4][64]  partial G
+    double* const dl = part + 2 * NSL * T * 256;     // [2][16][64]  deltas of a block
+    double* const bol = dl + 2 * 16 * 64;               // [2][16][64]  beta_old of a block
+    double* const gram = bol + 2 * 16 * 64;             // [2][16][16]  cg of a block (by columns)
+    double* const scl = gram + 2 * 256;                 // [2][16][4]   lod, xtx, row offset, -
+    volatile int* const prog = reinterpret_cast<volatile int*>(scl + 2 * 64);  // steps the chain has done
 
     if (*P.err != 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int s = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, kept scalar
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, kept scalar
     const int q = lane >> 4, r = lane & 15;
     const int n = P.n, d = P.d;
-    const int k0 = blockIdx.x * 16 * T;
-    const int row0 = s * 16 * KW4;
+    const int k0 = P.k_begin + blockIdx.x * 16 * T;
+    const int kend = P.k_end;
     const size_t pd = (size_t)P.p * d;
-    typedef const int __attribute__((address_space(4))) * JPtr;
-    const JPtr jidx = (JPtr)(unsigned long long)P.jidx;
+    const int nit = P.nblk + 2;
 
-    // chain role of this lane: response k0 + 16 q + r (q < T); every wave runs the whole
-    // chain, wave s stores the results of the steps t = s (mod S)
-    const int qc = (q < T) ? q : 0;
-    const int kc = k0 + 16 * qc + r;
-    const bool cvalid = (q < T) && (kc < d);
+    // response of this lane in the "one response per lane" role (chain, beta_old staging)
+    const int kc = k0 + lane;
+    const bool cvalid = (lane < 16 * T) && (kc < kend);
     const int kcs = cvalid ? kc : 0;
 
-    // ---- residual into registers: B operand of the dot MFMAs, C/D of the update MFMAs --
-    d4 rv[T][KW4];
-#pragma unroll
-    for (int tau = 0; tau < T; ++tau) {
-        const int k = k0 + 16 * tau + r;
-        const double* Rk = P.R + (size_t)(k < d ? k : 0) * n;
-#pragma unroll
-        for (int g = 0; g < KW; ++g) {
-            const int row = row0 + 4 * g + q;
-            rv[tau][g >> 2][g & 3] = (k < d && row < n) ? Rk[row] : 0.0;
-        }
-    }
-
-    double c_scale = 0.0, c_hinv = 0.0, c_cst = 0.0, c_s2 = 0.0;
-    if (cvalid) {
-        c_scale = P.scale[kc];
-        c_hinv = P.hinv[kc];
-        c_cst = P.cst[kc];
-        c_s2 = P.s2k[kc];
-    }
-    const double cfac = P.cfac;
-    double acc_g = 0.0, acc_m2 = 0.0, acc_b2 = 0.0;
-
-    // This wave's X operands form ONE stream in consumption order (KW dot operands, then
-    // the KW update operands k-slice by k-slice), two operands per 16-byte load.
-    const double2* xp = reinterpret_cast<const double2*>(P.XB) + ((size_t)s * KW) * 64 + lane;
-    constexpr size_t blk_skip = (size_t)(S - 1) * KW * 64;  // other waves' share, in pairs
-
-    // ---- block 0: beta_old, Gram and step scalars straight to LDS (parity 0) ---------
-    {
-        int j0[NBW];
-#pragma unroll
-        for (int u = 0; u < NBW; ++u) j0[u] = jidx[s + u * S];
-#pragma unroll
-        for (int u = 0; u < NBW; ++u)
-            bol[(s + u * S) * 64 + lane] = P.state[2 * pd + (size_t)j0[u] * d + kcs];
-    }
-    if (tid < 256) gram[tid] = P.gram[tid];
-    if (tid < 16) {
-        scl[2 * tid] = P.steps[tid].lod;
-        scl[2 * tid + 1] = P.steps[tid].xtx;
-    }
-
-    double2 ring[NR2];
-#pragma unroll
-    for (int i = 0; i < NR2; ++i) {
-        ring[i] = *xp;
-        xp += 64;
-    }
+    for (int e = tid; e < 2 * 16 * 64; e += NTHR) dl[e] = 0.0;  // deltas of blocks -2, -1
+    for (int e = tid; e < T * 256; e += NTHR)
+        part[(MW * T) * 256 + e] = 0.0;  // cross correction of block 0
+    if (tid == 0) *prog = 0;
+    __syncthreads();
 
 #ifdef LOCUS_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
-    for (int b = 0; b < P.nblk; ++b) {
-        const int par = b & 1;
-        const bool more = (b + 1 < P.nblk);
 
-        // prefetch for block b + 1 (rows past the last block exist: pack pads jidx / steps)
-        int jn[NBW];
-#pragma unroll
-        for (int u = 0; u < NBW; ++u) jn[u] = jidx[16 * (b + 1) + s + u * S];
-        double bo_nx[NBW];
-#pragma unroll
-        for (int u = 0; u < NBW; ++u) bo_nx[u] = P.state[2 * pd + (size_t)jn[u] * d + kcs];
-        const double gr_nx = (tid < 256) ? P.gram[(size_t)(b + 1) * 256 + tid] : 0.0;
-        double lod_nx = 0.0, xtx_nx = 0.0;
-        if (tid < 16) {
-            lod_nx = P.steps[16 * (b + 1) + tid].lod;
-            xtx_nx = P.steps[16 * (b + 1) + tid].xtx;
-        }
-        MSTAMP(6);  // issue of next block's operand loads
+    if (w != CW) {
+        const int m = (w > CW) ? w - 1 : w;  // logical matrix-wave index
+        // =========================== matrix role ==========================================
+        const int row0 = m * 16 * KT;
+        const CIntPtr jidx = (CIntPtr)(unsigned long long)P.jidx;
 
-        // ---- (1) G partial = X_J' R over this wave's rows ---------------------------
-        d4 acc[T];
+        // residual tiles: B operand of the dot MFMAs, C/D of the update MFMAs
+        d4 rv[T][KT];
 #pragma unroll
-        for (int tau = 0; tau < T; ++tau) acc[tau] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int tau = 0; tau < T; ++tau) {
+            const int k = k0 + 16 * tau + r;
+            const double* Rk = P.R + (size_t)(k < kend ? k : 0) * n;
 #pragma unroll
-        for (int g = 0; g < KW; ++g) {
-            const double a = (g & 1) ? ring[(g % NR) >> 1].y : ring[(g % NR) >> 1].x;
-            if (g & 1) {  // both operands of the pair consumed: request pair (g + NR) / 2
-                ring[(g % NR) >> 1] = *xp;
-                xp += 64;
+            for (int i = 0; i < KT; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = row0 + 16 * i + 4 * g + q;
+                    rv[tau][i][g] = (k < kend && row < n) ? Rk[row] : 0.0;
+                }
             }
+        }
+
+        // this wave's X operands: ONE contiguous stream in consumption order
+        const double2* xp =
+            reinterpret_cast<const double2*>(P.XS) + ((size_t)m * nit) * NPAIR * 64 + lane;
+        double2 ring[NR2];
+#pragma unroll
+        for (int i = 0; i < NR2; ++i) {
+            ring[i] = *xp;
+            xp += 64;
+        }
+        // staging registers, role by wave: wave XW -- A operands of the cross-block product
+        // X_it' X_{it-1} (axo[it + 1]); wave 1 -- Gram columns of block `it`; wave 2 -- its step
+        // scalars (both for the chain of iteration it + 1, through LDS)
+        double stg[4] = {0.0, 0.0, 0.0, 0.0};
+
+        for (int it = 0; it < nit; ++it) {
+            const int par = it & 1;
+            // beta_old of block `it` (the chain consumes it in iteration it + 1): rows w, w + 7, w + 14
+            double bo_ld[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int t = m + MW * u;
+                if (t < 16) {
+                    const int j = jidx[16 * it + t];
+                    bo_ld[u] = P.state[2 * pd + (size_t)j * d + kcs];
+                }
+            }
+            if (m == XW) {
+                if (it + 1 < nit) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        stg[c] = P.axo[((size_t)(it + 1) * 4 + c) * 64 + lane];
+                }
+            } else if (m == 1) {
+                const double2* gp = reinterpret_cast<const double2*>(P.cg + (size_t)it * 256) + 2 * lane;
+                const double2 g0 = gp[0], g1 = gp[1];
+                stg[0] = g0.x; stg[1] = g0.y; stg[2] = g1.x; stg[3] = g1.y;
+            } else if (m == 2) {
+                if (lane < 16 && it < P.nblk) {
+                    const StepRec* sr = P.steps + 16 * it + lane;
+                    stg[0] = sr->lod;
+                    stg[1] = sr->xtx;
+                    stg[2] = __longlong_as_double((long long)sr->j * d);
+                }
+            }
+
+            __syncthreads();  // B1: deltas of block it - 2 are in dl[par]
+            MSTAMP(0);
+            double bop[4][T];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int tau = 0; tau < T; ++tau)
+                    bop[c][tau] = dl[(par * 16 + 4 * c + q) * 64 + 16 * tau + r];
+
+            MSTAMP(1);
+
+            // one slot of the stream: operand o of this iteration
+            d4 acc[T][NACC];
 #pragma unroll
             for (int tau = 0; tau < T; ++tau)
-                acc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rv[tau][g >> 2][g & 3], acc[tau],
-                                                                0, 0, 0);
-        }
-        MSTAMP(0);  // dot MFMAs
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) acc[tau][a] = d4{0.0, 0.0, 0.0, 0.0};
 
-        // ---- (2) exchange partial G; one barrier per block ----------------------------
-        {
-            double* pb = part + ((par * S + s) * T) * 256 + lane;
-#pragma unroll
-            for (int tau = 0; tau < T; ++tau) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pb[tau * 256 + i * 64] = acc[tau][i];
-            }
-        }
-        MSTAMP(1);  // partial G to LDS
-        __syncthreads();
-        MSTAMP(2);  // barrier
-        // next block's beta_old / Gram / scalars: every wave is past its reads of that parity
-#pragma unroll
-        for (int u = 0; u < NBW; ++u) bol[((par ^ 1) * 16 + s + u * S) * 64 + lane] = bo_nx[u];
-        if (tid < 256) gram[(par ^ 1) * 256 + tid] = gr_nx;
-        if (tid < 16) {
-            scl[(par ^ 1) * 32 + 2 * tid] = lod_nx;
-            scl[(par ^ 1) * 32 + 2 * tid + 1] = xtx_nx;
-        }
-        MSTAMP(3);  // next block's operands to LDS
-
-        // ---- (3) the 16 sequential updates of the block, one response per lane, with the
-        //          rank-16 update of the residual riding in their shadow ------------------
-        // The operands of step t + 1 (beta_old, lod, xtx, partial G) are requested at the top
-        // of step t so that their LDS latency hides behind the exp / division chain.
-        // Once steps 4 kk .. 4 kk + 3 are done, the deltas of k-slice kk are known and its
-        // KW4 * T update MFMAs are issued between the instructions of steps 4 kk + 4 ..
-        // 4 kk + 7 (different pipe, independent registers); only the last k-slice runs
-        // after the chain.  The scheduling barrier at the end of each step bounds how far
-        // loads are hoisted (register pressure).
-        __builtin_amdgcn_sched_barrier(0);
-        double corr[kBlk];  // sum_{s<t} A_ts delta_s
-#pragma unroll
-        for (int t = 0; t < kBlk; ++t) corr[t] = 0.0;
-        const double* pr = part + ((par * S) * T + qc) * 256 + r;
-        const double* gm_l = gram + par * 256;
-        const double* sc_l = scl + par * 32;
-        const double* bo_l = bol + (par * 16) * 64 + lane;
-        double bo_c = bo_l[0];
-        double2 sc_c = *reinterpret_cast<const double2*>(sc_l);
-        double gp_c[S];
-#pragma unroll
-        for (int ss = 0; ss < S; ++ss) gp_c[ss] = pr[ss * T * 256];
-        int jc[kBlk];
-#pragma unroll
-        for (int t = 0; t < kBlk; ++t) jc[t] = jidx[16 * b + t];
-        double bop[T];
-        __builtin_amdgcn_sched_barrier(0);
-        sfor<kBlk>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            const bool act = 16 * b + t < P.nsteps;
-            // requests for step t + 1 and for the end of this step
-            double bo_n = 0.0;
-            double2 sc_n = make_double2(0.0, 0.0);
-            double gp_n[S];
-            sfor<S>([&](auto sc) { gp_n[decltype(sc)::value] = 0.0; });
-            if constexpr (t + 1 < kBlk) {
-                bo_n = bo_l[(t + 1) * 64];
-                sc_n = *reinterpret_cast<const double2*>(sc_l + 2 * (t + 1));
-                sfor<S>([&](auto sc) {
-                    constexpr int ss = decltype(sc)::value;
-                    gp_n[ss] = pr[ss * T * 256 + ((t + 1) >> 2) * 64 + 16 * ((t + 1) & 3)];
-                });
-            }
-            double gcol[kBlk];
-            sfor<kBlk - 1 - t>([&](auto c2) {
-                constexpr int t2 = t + 1 + decltype(c2)::value;
-                gcol[t2] = gm_l[t2 * 16 + t];
+            auto slot = [&](auto oc) {
+                constexpr int o = decltype(oc)::value;          // 0 .. NOP - 1
+                constexpr int sl = (o >> 1) % NR2;
+                const double a = (o & 1) ? ring[sl].y : ring[sl].x;
+                if constexpr ((o & 1) != 0) {  // pair consumed: request the pair NR2 loads ahead
+                    ring[sl] = *xp;
+                    xp += 64;
+                }
+                if constexpr (o < 4 * KT) {    // R += X_{it-2} d_{it-2}
+                    constexpr int i = op_tile(o, KT), c = op_sub(o, KT);
+                    sfor<T>([&](auto tc) {
+                        constexpr int tau = decltype(tc)::value;
+                        rv[tau][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[c][tau], rv[tau][i],
+                                                                          0, 0, 0);
+                    });
+                } else {                       // G_it partial = X_it' R over this wave's rows
+                    constexpr int i = op_tile(o - 4 * KT, KT), g = op_sub(o - 4 * KT, KT);
+                    sfor<T>([&](auto tc) {
+                        constexpr int tau = decltype(tc)::value;
+                        constexpr int a2 = (NACC == 2) ? (i & 1) : 0;
+                        acc[tau][a2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rv[tau][i][g],
+                                                                            acc[tau][a2], 0, 0, 0);
+                    });
+                }
+            };
+            sfor<4 * KT>(slot);
+            MSTAMP(3);
+            sfor<4 * KT>([&](auto oc) {
+                slot(std::integral_constant<int, 4 * KT + decltype(oc)::value>{});
             });
-            // B operands of the k-slice completed four steps ago
-            if constexpr (t >= 4 && (t & 3) == 0) {
-                sfor<T>([&](auto tc2) {
-                    constexpr int tau = decltype(tc2)::value;
-                    bop[tau] = dl[(4 * (t / 4 - 1) + q) * 64 + 16 * tau + r];
-                });
-            }
-
-            double u = gp_c[0];
-            sfor<S - 1>([&](auto sc) { u += gp_c[decltype(sc)::value + 1]; });
-            u += corr[t];
-            const double dot = fma(sc_c.y, bo_c, u);
-            const double m = c_scale * dot;                              // coreLoop.cpp:42-43
-            const double a = cfac * ((sc_c.x - m * m * c_hinv) + c_cst);  // :45-46
-            const double e = exp_nonpos(-fabs(a));
-            const double gmv = div_1to2((a >= 0.0) ? e : 1.0, 1.0 + e);
-            const double bn = m * gmv;                                   // :48
-            const double delta = (act && cvalid) ? (bo_c - bn) : 0.0;
-            sfor<kBlk - 1 - t>([&](auto c2) {
-                constexpr int t2 = t + 1 + decltype(c2)::value;
-                corr[t2] = fma(gcol[t2], delta, corr[t2]);
-            });
-            dl[t * 64 + lane] = delta;
-            if (act && cvalid && (t % S) == s) {
-                double* o = P.state + (size_t)jc[t] * d + kc;
-                o[0] = gmv;
-                o[pd] = m;
-                o[2 * pd] = bn;
-                acc_g += gmv;
-                acc_m2 = fma(gmv, fma(m, m, c_s2), acc_m2);
-                acc_b2 = fma(bn, bn, acc_b2);
-            }
-            if constexpr (t >= 4) {
-                // row tiles of k-slice kk handled in this step: i with 4 i / KW4 == t & 3
-                constexpr int kk = t / 4 - 1;
-                sfor<KW4>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    if constexpr ((4 * i) / KW4 == (t & 3)) LOCUS_UPD_SLOT(kk, i);
-                });
-            }
-            bo_c = bo_n;
-            sc_c = sc_n;
-            sfor<S>([&](auto sc) { gp_c[decltype(sc)::value] = gp_n[decltype(sc)::value]; });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        MSTAMP(4);  // chain (+ 3/4 of the update MFMAs)
-
-        // ---- (4) last k-slice of R += X_J delta ------------------------------------------
+            MSTAMP(4);
+            {
+                double* pb = part + ((par * NSL + m) * T) * 256 + lane;
 #pragma unroll
-        for (int tau = 0; tau < T; ++tau) bop[tau] = dl[(12 + q) * 64 + 16 * tau + r];
-        sfor<KW4>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            LOCUS_UPD_SLOT(3, i);
-        });
-        MSTAMP(5);  // update MFMAs
-    }
+                for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        double v = acc[tau][0][g];
+                        if constexpr (NACC == 2) v += acc[tau][1][g];
+                        pb[tau * 256 + g * 64] = v;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int t = m + MW * u;
+                if (t < 16) bol[(par * 16 + t) * 64 + lane] = bo_ld[u];
+            }
+            if (m == XW) {
+                // cross correction of block `it` from the deltas of block it - 1, which the chain
+                // wave is producing right now: follow its progress word
+                if (it >= 1 && it <= P.nblk) {
+                    d4 xc[T];
+#pragma unroll
+                    for (int tau = 0; tau < T; ++tau) xc[tau] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int target = 16 * (it - 1) + 4 * c + 4;
+                        while (*prog < target) __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int tau = 0; tau < T; ++tau) {
+                            const double bq = dl[((par ^ 1) * 16 + 4 * c + q) * 64 + 16 * tau + r];
+                            xc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[c], bq, xc[tau], 0, 0, 0);
+                        }
+                    }
+                    double* pb = part + ((par * NSL + MW) * T) * 256 + lane;
+#pragma unroll
+                    for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) pb[tau * 256 + g * 64] = xc[tau][g];
+                }
+            } else if (m == 1) {
+                double2* gd = reinterpret_cast<double2*>(gram + par * 256) + 2 * lane;
+                gd[0] = make_double2(stg[0], stg[1]);
+                gd[1] = make_double2(stg[2], stg[3]);
+            } else if (m == 2) {
+                if (lane < 16) {
+                    double2* sd = reinterpret_cast<double2*>(scl + (par * 16 + lane) * 4);
+                    sd[0] = make_double2(stg[0], stg[1]);
+                    sd[1] = make_double2(stg[2], 0.0);
+                }
+            }
+        }
 
 #ifdef LOCUS_STAMPS
-    if (tid == 0 && blockIdx.x < 4096)
-        for (int k = 0; k < 8; ++k) g_mfma_stamps[blockIdx.x * 8 + k] = tacc[k];
+        if (lane == 0 && m == (int)(blockIdx.x % MW) && blockIdx.x < 4096)
+            for (int k = 0; k < 5; ++k) g_mfma_stamps[blockIdx.x * 8 + k] = tacc[k];
 #endif
-    // ---- epilogue: residual back to memory, fused statistics ---------------------------
-    double ss2[T];
+        // residual back to memory; partial sums of squares for the fused statistics
+        __syncthreads();  // E1: the chain wave is done with `part`
+        // lane id and bounds are laundered so that the compiler does not keep the masks and
+        // addresses of the prologue loads alive (in SGPRs / VGPRs) across the whole sweep
+        int lane_e = lane, n_e = n, d_e = kend;
+        asm volatile("" : "+v"(lane_e));
+        asm volatile("" : "+s"(n_e), "+s"(d_e));
+        const int q_e = lane_e >> 4, r_e = lane_e & 15;
 #pragma unroll
-    for (int tau = 0; tau < T; ++tau) {
-        const int k = k0 + 16 * tau + r;
-        double* Rk = P.R + (size_t)(k < d ? k : 0) * n;
-        double a0 = 0.0;
+        for (int tau = 0; tau < T; ++tau) {
+            const int k = k0 + 16 * tau + r_e;
+            double* Rk = P.R + (size_t)(k < d_e ? k : 0) * n_e;
+            double a0 = 0.0;
 #pragma unroll
-        for (int g = 0; g < KW; ++g) {
-            const int row = row0 + 4 * g + q;
-            const double v = rv[tau][g >> 2][g & 3];
-            if (k < d && row < n) Rk[row] = v;
-            a0 = fma(v, v, a0);
+            for (int i = 0; i < KT; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = row0 + 16 * i + 4 * g + q_e;
+                    const double v = rv[tau][i][g];
+                    if (k < d_e && row < n_e) Rk[row] = v;
+                    a0 = fma(v, v, a0);
+                }
+            }
+            part[(m * T + tau) * 64 + lane] = a0;
         }
-        ss2[tau] = a0;
-    }
-    if (P.st != nullptr) {
-        __syncthreads();  // all waves are done with `part`
-        // part[s][tau][lane] <- partial sum of squares; the column statistics were accumulated
-        // by the wave that stored the step
+        __syncthreads();  // E2
+    } else {
+        // =========================== chain role ===========================================
+        double c_scale = 0.0, c_hinv = 0.0, c_cst = 0.0, c_s2 = 0.0;
+        if (cvalid) {
+            c_scale = P.scale[kc];
+            c_hinv = P.hinv[kc];
+            c_cst = P.cst[kc];
+            c_s2 = P.s2k[kc];
+        }
+        const double cfac = P.cfac;
+        double acc_g = 0.0, acc_m2 = 0.0, acc_b2 = 0.0;
+        const int qc = (q < T) ? q : 0;
+
+        for (int it = 0; it < nit; ++it) {
+            __syncthreads();  // B1
+            MSTAMP(7);
+            const int b = it - 1;  // block whose chain runs now
+            if (b < 0 || b >= P.nblk) continue;
+            const int par = b & 1;
+            const double* pr = part + ((par * NSL) * T + qc) * 256 + r;
+            const double* bo_l = bol + (par * 16) * 64 + lane;
+            double* dl_w = dl + (par * 16) * 64 + lane;
+            const double* gm_l = gram + par * 256;
+            const double* sc_l = scl + par * 64;
+
+            double corr[kBlk];  // sum_{s<t} A[t][s] delta_s
 #pragma unroll
-        for (int tau = 0; tau < T; ++tau) part[(s * T + tau) * 64 + lane] = ss2[tau];
-        double* sacc = part + S * T * 64;  // [S][3][64]
-        sacc[(s * 3 + 0) * 64 + lane] = acc_g;
-        sacc[(s * 3 + 1) * 64 + lane] = acc_m2;
-        sacc[(s * 3 + 2) * 64 + lane] = acc_b2;
-        __syncthreads();
-        if (cvalid && s == 0) {
-            double tot = 0.0, sg = 0.0, sm = 0.0, sb = 0.0;
+            for (int t = 0; t < kBlk; ++t) corr[t] = 0.0;
+            double bo_c = bo_l[0];
+            double2 sc_c = *reinterpret_cast<const double2*>(sc_l);
+            long long off_c = __double_as_longlong(sc_l[2]);
+            double ps_c;  // sum of the partial G of the current step over the slots
+            {
+                double g0[8];
+                g0[7] = 0.0;
 #pragma unroll
-            for (int ss = 0; ss < S; ++ss) {
+                for (int ss = 0; ss < NSL; ++ss) g0[ss] = pr[ss * T * 256];
+                ps_c = ((g0[0] + g0[1]) + (g0[2] + g0[3])) + ((g0[4] + g0[5]) + (g0[6] + g0[7]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sfor<kBlk>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const bool act = 16 * b + t < P.nsteps;
+                // requests for step t + 1
+                double bo_n = 0.0;
+                double2 sc_n = make_double2(0.0, 0.0);
+                long long off_n = 0;
+                double gp_n[8];
+                sfor<8>([&](auto sc) { gp_n[decltype(sc)::value] = 0.0; });
+                if constexpr (t + 1 < kBlk) {
+                    bo_n = bo_l[(t + 1) * 64];
+                    sc_n = *reinterpret_cast<const double2*>(sc_l + 4 * (t + 1));
+                    off_n = __double_as_longlong(sc_l[4 * (t + 1) + 2]);
+                    sfor<NSL>([&](auto sc) {
+                        constexpr int ss = decltype(sc)::value;
+                        gp_n[ss] = pr[ss * T * 256 + ((t + 1) >> 2) * 64 + 16 * ((t + 1) & 3)];
+                    });
+                }
+                // column t of the block's Gram matrix: needed after the exp / division chain
+                double gcol[kBlk];
+                sfor<kBlk - 1 - t>([&](auto c2) {
+                    constexpr int t2 = t + 1 + decltype(c2)::value;
+                    gcol[t2] = gm_l[t * 16 + t2];
+                });
+                const double lod = sc_c.x, xtx = sc_c.y;
+
+                const double u = ps_c + corr[t];
+                const double dot = fma(xtx, bo_c, u);
+                const double m = c_scale * dot;                            // coreLoop.cpp:42-43
+                const double a = cfac * ((lod - m * m * c_hinv) + c_cst);  // :45-46
+                const double e = exp_nonpos(-fabs(a));
+                const double gmv = div_1to2((a >= 0.0) ? e : 1.0, 1.0 + e);
+                const double bn = m * gmv;                                 // :48
+                const double delta = (act && cvalid) ? (bo_c - bn) : 0.0;
+                sfor<kBlk - 1 - t>([&](auto c2) {
+                    constexpr int t2 = t + 1 + decltype(c2)::value;
+                    corr[t2] = fma(gcol[t2], delta, corr[t2]);
+                });
+                dl_w[t * 64] = delta;
+                if constexpr ((t & 3) == 3) {
+                    // LDS executes a wave's accesses in order: a compiler barrier is enough to
+                    // publish the four deltas before the progress word
+                    asm volatile("" ::: "memory");
+                    *prog = 16 * b + t + 1;
+                }
+                if (act && cvalid) {
+                    double* o = P.state + off_c + kc;
+                    o[0] = gmv;
+                    o[pd] = m;
+                    o[2 * pd] = bn;
+                    acc_g += gmv;
+                    acc_m2 = fma(gmv, fma(m, m, c_s2), acc_m2);
+                    acc_b2 = fma(bn, bn, acc_b2);
+                }
+                bo_c = bo_n;
+                sc_c = sc_n;
+                off_c = off_n;
+                ps_c = ((gp_n[0] + gp_n[1]) + (gp_n[2] + gp_n[3])) +
+                       ((gp_n[4] + gp_n[5]) + (gp_n[6] + gp_n[7]));
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            MSTAMP(6);
+        }
+#ifdef LOCUS_STAMPS
+        if (lane == 0 && blockIdx.x < 4096)
+            for (int k = 5; k < 8; ++k) g_mfma_stamps[blockIdx.x * 8 + k] = tacc[k];
+#endif
+        __syncthreads();  // E1
+        __syncthreads();  // E2: partial sums of squares of the matrix waves are in `part`
+        if (P.st != nullptr && cvalid) {
+            double tot = 0.0;
+#pragma unroll
+            for (int ss = 0; ss < MW; ++ss) {
                 const double* pp = part + (ss * T + qc) * 64 + r;
                 tot += (pp[0] + pp[16]) + (pp[32] + pp[48]);
-                sg += sacc[(ss * 3 + 0) * 64 + lane];
-                sm += sacc[(ss * 3 + 1) * 64 + lane];
-                sb += sacc[(ss * 3 + 2) * 64 + lane];
             }
-            P.st[kc] = sg;
-            P.st[(size_t)d + kc] = sm;
-            P.st[2 * (size_t)d + kc] = sb;
+            P.st[kc] = acc_g;
+            P.st[(size_t)d + kc] = acc_m2;
+            P.st[2 * (size_t)d + kc] = acc_b2;
             P.st[3 * (size_t)d + kc] = tot;
         }
     }
 }
-#undef LOCUS_UPD_SLOT
 
 }  // namespace locus

@@ -60,13 +60,20 @@ def main():
             import ctypes
             fn = getattr(ctypes.CDLL(_lib.LIB_PATH), f"locus_hip_diag_read_mfma_stamps_{cfg[1]}")
             nwg = min(4096, (d + 16 * cfg[1] - 1) // (16 * cfg[1]))
+            MWV = 6 if cfg[1] == 1 else 7
             buf = (ctypes.c_ulonglong * (8 * nwg))()
             fn(buf, 8 * nwg)
-            a = np.array(buf, dtype=np.float64).reshape(nwg, 8)[:, :7] / ((nsteps + 15) // 16)
-            names = ["dot", "part->lds", "barrier", "next->lds", "chain", "update", "prefetch-issue"]
-            print("   cycles/block (median over WGs, wave 0): " +
-                  " ".join(f"{nm}={v:.0f}" for nm, v in zip(names, np.median(a, axis=0))) +
-                  f" total={np.median(a.sum(axis=1)):.0f}")
+            a = np.array(buf, dtype=np.float64).reshape(nwg, 8) / ((nsteps + 15) // 16 + 2)
+            names = ["w0:B1-wait", "w0:bop+xcorr", "w0:upd0+B2", "w0:update", "w0:dot", "-",
+                     "chain:run", "chain:wait"]
+            names = ["B1-wait", "bop+xcorr", "upd0+B2", "update", "dot"]
+            for wv in range(MWV):
+                aw = a[wv::MWV]
+                if len(aw):
+                    print(f"   ticks/iteration wave {wv}: " +
+                          " ".join(f"{nm}={v:.0f}" for nm, v in zip(names, np.median(aw[:, :5], axis=0))) +
+                          f" total={np.median(aw[:, :5].sum(axis=1)):.0f}")
+            print(f"   chain wave: run={np.median(a[:, 6]):.0f} wait={np.median(a[:, 7]):.0f}")
         elif "diag" in _lib.LIB_PATH:
             import ctypes
             c = cfg or tuple(cfg_used)

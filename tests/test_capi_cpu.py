@@ -38,10 +38,15 @@ def test_sweep_args_struct_matches_header():
 @pytest.mark.parametrize("n,d", [(200, 20), (1000, 1000), (1000, 1250), (1000, 10000),
                                  (2000, 500), (1000, 2000), (64, 1), (2048, 8)])
 @pytest.mark.parametrize("logit", [0, 1])
-def test_geometry_chooser(n, d, logit):
+def test_geometry_chooser(n, d, logit, monkeypatch):
     from locus_amd import _lib
     cfg = (ctypes.c_int32 * 4)()
     _lib.check(_lib.lib().locus_hip_sweep_config(n, d, logit, cfg))
+    if not logit and n <= 2016:
+        # identity family: the matrix-core sweep, planned from d at launch time
+        assert list(cfg) == [-1, 0, 0, 0]
+        monkeypatch.setenv("LOCUS_HIP_SWEEP_VECTOR", "1")
+        _lib.check(_lib.lib().locus_hip_sweep_config(n, d, logit, cfg))
     npl, c, s, g = list(cfg)
     assert npl in (2, 4, 8, 16) and 64 * npl * s >= n and 64 * s * g <= 1024
     assert 2 * npl * c * (2 if logit else 1) <= 170  # residual fits the 256-VGPR budget

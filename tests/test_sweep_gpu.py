@@ -82,14 +82,14 @@ def test_two_sweeps_in_a_row_deterministic(hip):
 
 # matrix-core kernel, explicit geometries -1,T,S,KW4 (T tiles of 16 responses per workgroup,
 # S waves, KW4 16-row tiles per wave): ragged rows / responses / last block of the sweep
-MFMA_GEOMS = ["-1,1,4,1", "-1,2,4,1", "-1,2,4,2", "-1,1,8,2", "-1,2,4,4", "-1,1,4,4", "-1,1,4,8",
-              "-1,2,8,4", "-1,1,4,16", "-1,2,4,16", "-1,2,4,8", "-1,1,8,16", "-1,2,8,8"]
+MFMA_GEOMS = ["-1,1,8,2", "-1,2,8,2", "-1,1,8,4", "-1,2,8,4", "-1,1,8,6", "-1,2,8,6", "-1,1,8,8",
+              "-1,2,8,9", "-1,1,8,11", "-1,1,8,21", "-1,1,8,0", "-1,2,8,0"]
 
 
 @pytest.mark.parametrize("geom", MFMA_GEOMS)
 def test_mfma_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
-    _, t, s, kw4 = map(int, geom.split(","))
-    n = 16 * kw4 * s - 5
+    _, t, _, kt = map(int, geom.split(","))
+    n = (6 if t == 1 else 7) * 16 * kt - 5 if kt else 300   # matrix waves x 16-row tiles
     p, d = 53, 16 * t + 16 * t + 7    # 3 blocks + 5 steps; partial last workgroup / tile
     inp = inputs_for("identity", n, p, d, seed=21)
     ref = call_variant(oracle, "identity", inp)
@@ -99,13 +99,11 @@ def test_mfma_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["identity", "z", "struct", "probit"])
-@pytest.mark.parametrize("shape", [(200, 500, 20), (1000, 64, 41), (100, 16, 3), (64, 7, 1)])
+@pytest.mark.parametrize("shape", [(200, 500, 20), (1000, 64, 41), (100, 16, 3), (64, 7, 1),
+                                   (333, 1, 5), (500, 33, 70)])
 def test_mfma_sweep_variants(oracle, hip, variant, shape, monkeypatch):
     n, p, d = shape
-    kw4 = 1
-    while 64 * kw4 < n:
-        kw4 *= 2
-    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-1,{1 if d <= 16 else 2},4,{kw4}")
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-1,{1 if d <= 16 else 2},8,0")
     inp = inputs_for(variant, n, p, d, seed=n + p + d, c=0.6 if variant == "identity" else 1.0)
     ref = call_variant(oracle, variant, inp)
     got = call_variant(hip, variant, inp)
