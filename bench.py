@@ -13,12 +13,14 @@ With --gpus N the d responses are sharded over N ranks (X replicated, one RCCL
 all-reduce of p + 2 doubles per step): total work is fixed => "scaling": "strong".
 
 The JSON line also carries
-  roofline     : the sweep kernel against the HBM roofline with the ALGORITHMIC bytes of
-                 SURVEY.md §8(d) (16 n + 8 n / d_loc + 32 per update).  The residual lives
-                 in VGPRs for the whole sweep, so the fraction exceeds 1 -- the binding
-                 roofline is fp64 FMA, reported as roofline_fp64 (4 n + 60 flop / update,
-                 78.6 TFLOP/s peak).  `traffic` is the PMC-measured HBM bytes per launch
-                 from profiles/ (null if no profile of this shape is committed).
+  roofline     : the sweep (one call of locus_hip_sweep_dev = block packing + the matrix-core
+                 sweep launches that together visit all p x d_loc pairs) against the HBM
+                 roofline with the ALGORITHMIC bytes of SURVEY.md §8(d) (16 n + 8 n / d_loc + 32
+                 per update).  The residual lives in registers for the whole sweep, so the
+                 fraction exceeds 1 -- the binding roofline is fp64 (matrix cores == vector
+                 peak, 78.6 TFLOP/s), reported as roofline_fp64 (4 n + 60 flop / update).
+                 `traffic` is the PMC-measured HBM bytes per sweep from profiles/ (null if
+                 no profile of this shape is committed).
   cpu_baseline : the C oracle (literal restatement of src/coreLoop.cpp, gcc -O2, 1 thread)
                  timed on this host on a bounded sample of the same workload.
 """
@@ -229,11 +231,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": committed_traffic(n, p, d_loc),
-                         "kernel": "sweep_kernel (coreLoop)", "kernel_ms": kern_ms,
+                         "kernel": "coreLoop sweep = pack_blocks_kernel + mfma_sweep_kernel "
+                                   "launches (T=2 for the first 32 responses per CU, T=1 for "
+                                   "the rest)", "kernel_ms": kern_ms,
                          "bytes_per_update": bytes_per_update, "updates_per_launch": upd_launch,
                          "note": "algorithmic bytes of SURVEY §8(d); residual is register-"
                                  "resident so frac > 1 is expected, see roofline_fp64"},
-            "roofline_fp64": {"bound": "fp64-fma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
+            "roofline_fp64": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
                               "flops_per_update": flops_per_update},
         }

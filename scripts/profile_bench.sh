@@ -7,6 +7,7 @@
 set -e
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
+rm -rf $OUT
 mkdir -p $OUT
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1

@@ -5,11 +5,12 @@ import csv, glob, json, os, shutil, sys
 tag, n, p, d_loc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 src = "gpurun_out/prof"
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True)[0]
+stats = max(glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
 shutil.copy(stats, f"profiles/{tag}_bench_kernel_stats.csv")
 
 def counter(dirname, name):
-    f = glob.glob(f"{src}/{dirname}/**/*_counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(f"{src}/{dirname}/**/*_counter_collection.csv", recursive=True),
+            key=os.path.getmtime)
     rows = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name:
@@ -22,7 +23,19 @@ lines = ["# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py 
          "# MI355X_MICROARCH.md §HBM (FETCH_SIZE reports 1/2 of wide coalesced reads) = 2 x FETCH_SIZE",
          "kernel,calls,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_read_bytes,hbm_write_bytes"]
 traffic = []
-for k in fetch:
+# one sweep = the kernels locus_hip_sweep_dev launches; build_steps_kernel runs once per sweep
+nsweeps = max([len(v) for k, v in fetch.items() if "build_steps_kernel" in k] + [1])
+seq = [k for k in fetch if "mfma_sweep_kernel" in k or "pack_blocks_kernel" in k or
+       "sweep_kernel" in k or "build_steps_kernel" in k]
+if seq:
+    rd = sum(sum(fetch[k]) for k in seq) * 2 * 1024 / nsweeps
+    wr = sum(sum(write.get(k, [0])) for k in seq) * 1024 / nsweeps
+    traffic.append(dict(n=n, p=p, d_loc=d_loc, kernel="sweep sequence: " + "; ".join(
+                            f"{k[:60]} x{len(fetch[k]) / nsweeps:g}" for k in seq),
+                        hbm_bytes_per_launch=rd + wr, hbm_read_bytes=rd, hbm_write_bytes=wr,
+                        correction="2 x FETCH_SIZE (gfx950, 16-B coalesced loads) + WRITE_SIZE, "
+                                   "summed over the kernels of one sweep"))
+for k in []:
     fs = sum(fetch[k]) / len(fetch[k])
     ws = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
     lines.append(f"\"{k[:80]}\",{len(fetch[k])},{fs:.1f},{ws:.1f},{2*fs*1024:.4e},{ws*1024:.4e}")
