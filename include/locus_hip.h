@@ -151,7 +151,8 @@ typedef struct locus_hip_sweep_args {
     int64_t nsteps;             /* covariates to visit (0 or p = full sweep)          */
     int32_t cfg[4];             /* NPL, C, S, G kernel geometry; all 0 = automatic;
                                    NPL = -1: matrix-core kernel with C = tiles of 16 responses
-                                   per workgroup, S = waves, G = 16-row tiles per wave */
+                                   per workgroup (1, 2; 0 = planned from d), S ignored,
+                                   G = 16-row tiles per matrix wave (0 = smallest that fits n) */
 } locus_hip_sweep_args;
 
 /* One CAVI sweep over the covariates in `shuffled_ind` order; logit = 0 runs the
@@ -163,7 +164,8 @@ int locus_hip_sweep_dev(const locus_hip_sweep_args* args, int logit, void* strea
  * `workspace` (sized for p covariates) was given an invalid shuffled_ind. */
 int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream);
 
-/* Geometry the library would pick for (n, d): fills cfg[4] = NPL, C, S, G. */
+/* Geometry the library would pick for (n, d): fills cfg[4] = NPL, C, S, G
+ * ({-1, 0, 0, 0}: the matrix-core sweep, launches planned from d). */
 int locus_hip_sweep_config(int64_t n, int64_t d, int logit, int32_t* cfg);
 
 /* out = Y - A - Zmu                       (W2 == NULL; same formula both directions)
