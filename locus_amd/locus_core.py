@@ -56,23 +56,63 @@ class IdentityHost(HostBase):
         self.tau_vb = np.array(tau_vb, dtype=np.float64)
         self.sig2_beta_vb = np.array(sig2_beta_vb, dtype=np.float64)
         self.sig2_inv_vb = None
-        self.rs_gam = self.sum_gam = self.sum_tau_m2 = None
+        self.sum_gam = self.sum_tau_m2 = None
         self.stats = None
-        self.a_vb = self.b_vb = self.om_vb = None
+        # length-p quantities live where rowSums(gam) lives (the GPU; CPU tensors in the CPU
+        # tests): the all-reduced buffer never comes back to the host, only scalars do
+        self.rs_gam_t = self.a_t = self.b_t = None
+        self._digam_sum, self._c_last = {}, 1.0
+
+    def _reduce_p(self, rs_gam_local, scalars):
+        """ONE all-reduce of [rowSums(gam) (p) | scalars]; rowSums stays a tensor on its
+        device, the scalars (+ sum(rs_gam)) come back to the host."""
+        import torch
+        dev = rs_gam_local.device
+        if self.a_t is None or self.a_t.device != dev:
+            self.a_t = torch.from_numpy(self.a).to(dev)
+            self.b_t = torch.from_numpy(self.b).to(dev)
+            self._digam_sum = {}
+        tail = torch.as_tensor(np.asarray(scalars, dtype=np.float64).reshape(-1), device=dev)
+        buf = torch.cat([rs_gam_local.reshape(-1), tail])
+        self.comm.all_reduce_sum_(buf)
+        self.rs_gam_t = buf[: self.p]
+        h = torch.cat([buf[self.p:], self.rs_gam_t.sum().reshape(1)]).cpu().numpy()
+        self.sum_gam = float(h[-1])
+        return h[:-1]
+
+    # length-p results for the caller (R/locus_core.R:242-252), on the host
+    @property
+    def rs_gam(self):
+        return self.rs_gam_t.cpu().numpy()
+
+    @property
+    def a_vb(self):
+        return U.update_a_vb(self.a, self.rs_gam, self._c_last)
+
+    @property
+    def b_vb(self):
+        return U.update_b_vb(self.b, self.d, self.rs_gam, self._c_last)
+
+    @property
+    def om_vb(self):
+        a_vb, b_vb = self.a_vb, self.b_vb
+        return a_vb / (a_vb + b_vb)
 
     def set_initial(self, stats, rs_gam_local):
         """R/locus_core.R:36-42: statistics of the initial gam_vb / mu_beta_vb."""
         self.stats = np.asarray(stats, dtype=np.float64)
         t_loc = float(self.tau_vb @ self.stats[1])
-        self.rs_gam, sc = self._all_reduce(rs_gam_local, [t_loc])
-        self.sum_gam = float(self.rs_gam.sum())
+        sc = self._reduce_p(rs_gam_local, [t_loc])
         self.sum_tau_m2 = float(sc[0])
 
     # -- top of the iteration: R/locus_core.R:57-84 ----------------------------
     def begin_iteration(self, c=1.0):
         n, d = self.n, self.d
+        import torch
         cs_gam, cs_m2, cs_b2, rss = self.stats
-        digam_sum = digamma(c * (self.a + self.b + d) - 2 * c + 2)
+        if c not in self._digam_sum:
+            self._digam_sum = {c: torch.digamma(c * (self.a_t + self.b_t + d) - 2 * c + 2)}
+        digam_sum = self._digam_sum[c]
         lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam, c)
         nu_vb = U.update_nu_vb_(self.nu, self.sum_tau_m2, c)
         self.sig2_inv_vb = lambda_vb / nu_vb
@@ -82,8 +122,10 @@ class IdentityHost(HostBase):
         self.sig2_beta_vb = U.update_sig2_beta_vb_(n, self.sig2_inv_vb, self.tau_vb, c)
         log_tau_vb = U.update_log_tau_vb_(eta_vb, kappa_vb)
         log_sig2_inv_vb = U.update_log_sig2_inv_vb_(lambda_vb, nu_vb)
-        log_om_vb = U.update_log_om_vb(self.a, digam_sum, self.rs_gam, c)
-        log_1_min_om_vb = U.update_log_1_min_om_vb(self.b, d, digam_sum, self.rs_gam, c)
+        # R/update_vb.R:187,190 on the device that holds rowSums(gam)
+        rs = self.rs_gam_t
+        log_om_vb = torch.digamma(c * (self.a_t + rs) - c + 1) - digam_sum
+        log_1_min_om_vb = torch.digamma(c * (self.b_t - rs + d) - c + 1) - digam_sum
         s2 = self.sig2_beta_vb
         return dict(
             lo=log_om_vb, l1=log_1_min_om_vb, log_sig2_inv_vb=float(log_sig2_inv_vb),
@@ -107,25 +149,31 @@ class IdentityHost(HostBase):
             abc_loc = (E.e_y_(n, self.kappa, kappa_vb, log_tau_vb, cs_m2, si, tau)
                        + E.e_beta_gamma_local_(cs_gam, cs_m2, ent_local, log_tau_vb, s2, si, tau)
                        + E.e_tau_(self.eta, eta_vb, self.kappa, kappa_vb, log_tau_vb, tau))
-        self.rs_gam, sc = self._all_reduce(rs_gam_local, [t_loc, abc_loc])
+        import torch
+        sc = self._reduce_p(rs_gam_local, [t_loc, abc_loc])
         self.sum_tau_m2 = float(sc[0])
-        self.a_vb = U.update_a_vb(self.a, self.rs_gam, c)
-        self.b_vb = U.update_b_vb(self.b, d, self.rs_gam, c)
-        self.om_vb = self.a_vb / (self.a_vb + self.b_vb)
-        self.sum_gam = float(self.rs_gam.sum())
+        self._c_last = c
         if not with_elbo:
             return None
+        # covariate-wise terms of elbo_ (R/locus_core.R:270-275; R/elbo.R:43-54, 114-118) where
+        # rowSums(gam) lives; two scalars come back
+        rs, a, b = self.rs_gam_t, self.a_t, self.b_t
+        a_vb = a + rs                                    # update_a_vb / update_b_vb with c = 1
+        b_vb = b - rs + d
+        dg = torch.digamma(a_vb + b_vb)
+        log_om_vb = torch.digamma(a_vb) - dg
+        log_1_min_om_vb = torch.digamma(b_vb) - dg
+        lbeta = lambda x, y: torch.lgamma(x) + torch.lgamma(y) - torch.lgamma(x + y)
+        s_bg = (rs * log_om_vb).sum() + ((d - rs) * log_1_min_om_vb).sum()
+        e_om = ((a - a_vb) * log_om_vb + (b - b_vb) * log_1_min_om_vb - lbeta(a, b)
+                + lbeta(a_vb, b_vb)).sum()
+        s_bg, e_om = torch.stack([s_bg, e_om]).cpu().numpy()
         lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam)
         nu_vb = U.update_nu_vb_(self.nu, self.sum_tau_m2)
         log_sig2_inv_vb = digamma(lambda_vb) - np.log(nu_vb)
-        log_om_vb = digamma(self.a_vb) - digamma(self.a_vb + self.b_vb)
-        log_1_min_om_vb = digamma(self.b_vb) - digamma(self.a_vb + self.b_vb)
-        return float(sc[1]
-                     + E.e_beta_gamma_global_(self.rs_gam, self.sum_gam, d, log_om_vb,
-                                              log_1_min_om_vb, log_sig2_inv_vb)
+        return float(sc[1] + log_sig2_inv_vb * self.sum_gam / 2 + s_bg
                      + E.e_sig2_inv_(self.lam, lambda_vb, log_sig2_inv_vb, self.nu, nu_vb, si)
-                     + E.e_omega_(self.a, self.a_vb, self.b, self.b_vb, log_om_vb,
-                                  log_1_min_om_vb))
+                     + e_om)
 
 
 class IdentityEngine:
@@ -145,6 +193,8 @@ class IdentityEngine:
         self.R = None
 
     def _up(self, a):
+        if self.torch.is_tensor(a):
+            return a
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
 
     def initialise(self):
