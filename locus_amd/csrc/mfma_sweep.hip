@@ -26,7 +26,8 @@ int launch_mfma_sweep_t2(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStr
 __global__ void __launch_bounds__(256)
 pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ steps,
                    double* __restrict__ XS, double* __restrict__ cg, double* __restrict__ axo,
-                   int* __restrict__ jidx, int ld, int KT, int nblk, int MW)
+                   double* __restrict__ sc4, int* __restrict__ jidx, int ld, int KT, int nblk, int MW,
+                   int d)
 {
     __shared__ double xt[16][130];
     __shared__ double xn[16][130];
@@ -38,6 +39,11 @@ pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ st
         js[tid] = has ? steps[16 * b + tid].j : 0;
         jn[tid] = has_next ? steps[16 * (b + 1) + tid].j : 0;
         jidx[16 * b + tid] = js[tid];
+        double* sc = sc4 + (size_t)(16 * b + tid) * 4;
+        sc[0] = has ? steps[16 * b + tid].lod : 0.0;
+        sc[1] = has ? steps[16 * b + tid].xtx : 0.0;
+        sc[2] = __longlong_as_double((long long)js[tid] * d);
+        sc[3] = 0.0;
     }
     const int rows_pad = MW * 16 * KT;
     const int NOP = 8 * KT;
@@ -88,8 +94,8 @@ pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ st
     cg[(size_t)b * 256 + gs * 16 + gt] = (gt > gs) ? gacc : 0.0;
     // cross Gram (X_{b+1}' X_b)[t' = gt][t = gs] as A operand c = gs >> 2, lane (gs & 3) * 16 + gt,
     // consumed in iteration b + 2
-    if (b + 2 < nit) axo[((size_t)(b + 2) * 4 + (gs >> 2)) * 64 + (gs & 3) * 16 + gt] = xacc;
-    if (b < 2) axo[((size_t)b * 4 + (gs >> 2)) * 64 + (gs & 3) * 16 + gt] = 0.0;
+    if (b + 2 < nit) axo[((size_t)(b + 2) * 64 + (gs & 3) * 16 + gt) * 4 + (gs >> 2)] = xacc;
+    if (b < 2) axo[((size_t)b * 64 + (gs & 3) * 16 + gt) * 4 + (gs >> 2)] = 0.0;
 }
 
 // row tiles of 16 per matrix wave for n rows: the instantiated KT values
@@ -109,8 +115,8 @@ size_t mfma_workspace_bytes(int64_t n, int64_t p)
     const int kt1 = mfma_kt_for(n, 1), kt2 = mfma_kt_for(n, 2);
     if (kt1 == 0) return 1024;  // the matrix-core sweep does not cover this n
     const size_t rows_pad = std::max((size_t)mfma_waves(1) * 16 * kt1, (size_t)mfma_waves(2) * 16 * kt2);
-    return sizeof(double) * (nit * rows_pad * 32 + 2 * nit * 256) + sizeof(int) * 16 * nit +
-           32 * 1024;
+    return sizeof(double) * (nit * rows_pad * 32 + 2 * nit * 256 + nit * 64) + sizeof(int) * 16 * nit +
+           64 * 1024;
 }
 
 size_t mfma_lds_bytes(int T)
@@ -146,7 +152,7 @@ static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, i
     const int nblk = (prm.nsteps + 15) / 16;
     const size_t nit = (size_t)nblk + 2;
     const size_t xs = nit * rows_pad * 32;  // doubles of the packed operand streams
-    if (sizeof(double) * (xs + 2 * nit * 256) + sizeof(int) * 16 * nit + 32 * 1024 > xb_bytes) {
+    if (sizeof(double) * (xs + 2 * nit * 256 + nit * 64) + sizeof(int) * 16 * nit + 64 * 1024 > xb_bytes) {
         set_error("mfma sweep: workspace too small");
         return LOCUS_HIP_EINVAL;
     }
@@ -155,11 +161,12 @@ static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, i
     double* XS = reinterpret_cast<double*>(base);
     double* cgp = XS + xs + 2048;  // 16 KB of slack: the operand ring reads ahead of the stream
     double* axo = cgp + nit * 256;
-    int* jidx = reinterpret_cast<int*>(axo + nit * 256);
+    double* sc4 = axo + (nit + 1) * 256;  // one iteration of slack: staged one block ahead
+    int* jidx = reinterpret_cast<int*>(sc4 + nit * 64 + 256);
 
     if (pack) {
         hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)nit), dim3(256), 0, st, prm.Xp,
-                           prm.steps, XS, cgp, axo, jidx, prm.ld, KT, nblk, MW);
+                           prm.steps, XS, cgp, axo, sc4, jidx, prm.ld, KT, nblk, MW, prm.d);
         LOCUS_HIP_CHECK(hipGetLastError());
     }
 
@@ -168,7 +175,7 @@ static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, i
     mp.k_begin = k_begin; mp.k_end = k_end;
     mp.nblk = nblk; mp.nsteps = prm.nsteps;
     mp.steps = prm.steps; mp.err = prm.err;
-    mp.XS = XS; mp.cg = cgp; mp.axo = axo; mp.jidx = jidx;
+    mp.XS = XS; mp.cg = cgp; mp.axo = axo; mp.sc4 = sc4; mp.jidx = jidx;
     mp.scale = prm.scale; mp.hinv = prm.hinv; mp.cst = prm.cst; mp.s2k = prm.s2k;
     mp.cfac = prm.cfac;
     mp.R = prm.R; mp.state = prm.state; mp.st = prm.st;

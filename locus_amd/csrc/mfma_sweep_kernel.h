@@ -89,7 +89,9 @@ struct MfmaSweepParams {
                          // operands of block it - 2 then the 4 KT dot operands of block it,
                          // consecutive operands paired per lane (one 16-byte load = 2 operands)
     const double* cg;    // [nblk + 2][16][16]: cg[b][t][t'] = X_t' X_t' of block b for t' > t, else 0
-    const double* axo;   // [nblk + 2][4][64]: X_{it-1}' X_{it-2} as the 4 A operands of a 16x16x16 product
+    const double* axo;   // [nblk + 2][64][4]: X_{it-1}' X_{it-2} as the 4 A operands (per lane) of a
+                         // 16x16x16 product
+    const double* sc4;   // [16 * (nblk + 2)][4]: lod, xtx, bits of (long long) j * d, 0 of every step
     const int* jidx;     // [16 * (nblk + 2)]  covariate index of every step (tail: 0)
     const double* scale; // per-response constants, as SweepParams
     const double* hinv;
@@ -223,41 +225,27 @@ mfma_sweep_kernel(const MfmaSweepParams P)
             ring[i] = *xp;
             xp += 64;
         }
-        // staging registers, role by wave: wave XW -- A operands of the cross-block product
-        // X_it' X_{it-1} (axo[it + 1]); wave 1 -- Gram columns of block `it`; wave 2 -- its step
-        // scalars (both for the chain of iteration it + 1, through LDS)
-        double stg[4] = {0.0, 0.0, 0.0, 0.0};
+        // Staging jobs, one shape for every wave (two 16-byte loads per lane in the middle of the
+        // iteration, consumed at its end, nothing carried across iterations):
+        //   wave XW: A operands of the cross-block product X_{it+1}' X_it   (axo[it + 1], in registers)
+        //   wave 1 : Gram columns of block `it`                              (cg  -> LDS `gram`)
+        //   wave 2 : step scalars {lod, xtx, row offset} of block `it`       (sc4 -> LDS `scl`)
+        // The others load the Gram columns too and drop them (uniform code, no per-role registers).
+        const double* stg_src = P.cg + 4 * lane;
+        size_t stg_stride = 256;
+        if (m == XW) {
+            stg_src = P.axo + 256 + 4 * lane;
+        } else if (m == 2) {
+            stg_src = P.sc4 + 4 * (lane & 15);
+            stg_stride = 64;
+        }
 
         for (int it = 0; it < nit; ++it) {
             const int par = it & 1;
-            // beta_old of block `it` (the chain consumes it in iteration it + 1): rows w, w + 7, w + 14
-            double bo_ld[3] = {0.0, 0.0, 0.0};
+            // covariates of the rows of block `it` whose beta_old this wave stages: m, m + MW, m + 2 MW
+            int jn[3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int t = m + MW * u;
-                if (t < 16) {
-                    const int j = jidx[16 * it + t];
-                    bo_ld[u] = P.state[2 * pd + (size_t)j * d + kcs];
-                }
-            }
-            if (m == XW) {
-                if (it + 1 < nit) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        stg[c] = P.axo[((size_t)(it + 1) * 4 + c) * 64 + lane];
-                }
-            } else if (m == 1) {
-                const double2* gp = reinterpret_cast<const double2*>(P.cg + (size_t)it * 256) + 2 * lane;
-                const double2 g0 = gp[0], g1 = gp[1];
-                stg[0] = g0.x; stg[1] = g0.y; stg[2] = g1.x; stg[3] = g1.y;
-            } else if (m == 2) {
-                if (lane < 16 && it < P.nblk) {
-                    const StepRec* sr = P.steps + 16 * it + lane;
-                    stg[0] = sr->lod;
-                    stg[1] = sr->xtx;
-                    stg[2] = __longlong_as_double((long long)sr->j * d);
-                }
-            }
+            for (int u = 0; u < 3; ++u) jn[u] = jidx[16 * it + ((m + MW * u) & 15)];
 
             __syncthreads();  // B1: deltas of block it - 2 are in dl[par]
             MSTAMP(0);
@@ -304,6 +292,14 @@ mfma_sweep_kernel(const MfmaSweepParams P)
             };
             sfor<4 * KT>(slot);
             MSTAMP(3);
+            // staging loads of block `it` (latency hidden behind the dot MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
+            double bo_ld[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) bo_ld[u] = P.state[2 * pd + (size_t)jn[u] * d + kcs];
+            const double2 sg0 = *reinterpret_cast<const double2*>(stg_src + (size_t)it * stg_stride);
+            const double2 sg1 = *reinterpret_cast<const double2*>(stg_src + (size_t)it * stg_stride + 2);
+            __builtin_amdgcn_sched_barrier(0);
             sfor<4 * KT>([&](auto oc) {
                 slot(std::integral_constant<int, 4 * KT + decltype(oc)::value>{});
             });
@@ -324,10 +320,19 @@ mfma_sweep_kernel(const MfmaSweepParams P)
                 const int t = m + MW * u;
                 if (t < 16) bol[(par * 16 + t) * 64 + lane] = bo_ld[u];
             }
-            if (m == XW) {
+            if (m == 1) {
+                double2* gd = reinterpret_cast<double2*>(gram + par * 256) + 2 * lane;
+                gd[0] = sg0;
+                gd[1] = sg1;
+            } else if (m == 2) {
+                double2* sd = reinterpret_cast<double2*>(scl + (par * 16 + (lane & 15)) * 4);
+                sd[0] = sg0;
+                sd[1] = sg1;
+            } else if (m == XW) {
                 // cross correction of block `it` from the deltas of block it - 1, which the chain
                 // wave is producing right now: follow its progress word
                 if (it >= 1 && it <= P.nblk) {
+                    const double ax[4] = {sg0.x, sg0.y, sg1.x, sg1.y};
                     d4 xc[T];
 #pragma unroll
                     for (int tau = 0; tau < T; ++tau) xc[tau] = d4{0.0, 0.0, 0.0, 0.0};
@@ -339,7 +344,7 @@ mfma_sweep_kernel(const MfmaSweepParams P)
 #pragma unroll
                         for (int tau = 0; tau < T; ++tau) {
                             const double bq = dl[((par ^ 1) * 16 + 4 * c + q) * 64 + 16 * tau + r];
-                            xc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[c], bq, xc[tau], 0, 0, 0);
+                            xc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[c], bq, xc[tau], 0, 0, 0);
                         }
                     }
                     double* pb = part + ((par * NSL + MW) * T) * 256 + lane;
@@ -347,16 +352,6 @@ mfma_sweep_kernel(const MfmaSweepParams P)
                     for (int tau = 0; tau < T; ++tau)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) pb[tau * 256 + g * 64] = xc[tau][g];
-                }
-            } else if (m == 1) {
-                double2* gd = reinterpret_cast<double2*>(gram + par * 256) + 2 * lane;
-                gd[0] = make_double2(stg[0], stg[1]);
-                gd[1] = make_double2(stg[2], stg[3]);
-            } else if (m == 2) {
-                if (lane < 16) {
-                    double2* sd = reinterpret_cast<double2*>(scl + (par * 16 + lane) * 4);
-                    sd[0] = make_double2(stg[0], stg[1]);
-                    sd[1] = make_double2(stg[2], 0.0);
                 }
             }
         }
