@@ -14,3 +14,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
 find $OUT -name "*.csv" | head -20
+# 4. matrix-core utilisation (own pass): MFMA busy cycles against CU busy cycles, per kernel
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 $ARGS > $OUT/mfma.log 2>&1 || echo "mfma pass failed (see mfma.log)"

@@ -48,3 +48,26 @@ open(f"profiles/{tag}_bench_hbm_counters.csv", "w").write("\n".join(lines) + "\n
 json.dump(traffic, open(f"profiles/traffic_{tag}.json", "w"), indent=1)
 print("\n".join(lines[:12]))
 print(traffic)
+
+# matrix-core utilisation (own --pmc pass): SQ_VALU_MFMA_BUSY_CYCLES counts SIMD-cycles with an MFMA
+# in flight, SQ_BUSY_CU_CYCLES counts CU-cycles with waves resident => util = MFMA / (4 SIMDs x CU)
+mf = glob.glob(f"{src}/mfma/**/*_counter_collection.csv", recursive=True)
+if mf:
+    import collections
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(max(mf, key=os.path.getmtime))):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE, bench.py --steps 3 --warmup 1",
+           "# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES): share of the SIMD-cycles of the",
+           "# busy CUs in which a matrix-core instruction executes (fp64 MFMA peak 78.6 TFLOP/s = 100 %)",
+           "kernel,calls,SQ_VALU_MFMA_BUSY_CYCLES_avg,SQ_BUSY_CU_CYCLES_avg,GRBM_GUI_ACTIVE_avg,mfma_util"]
+    for k, v in acc.items():
+        m = v.get("SQ_VALU_MFMA_BUSY_CYCLES", [0.0])
+        if sum(m) == 0:
+            continue
+        avg = lambda c: sum(v[c]) / len(v[c]) if v.get(c) else 0.0
+        out.append(f"\"{k[:80]}\",{len(m)},{avg('SQ_VALU_MFMA_BUSY_CYCLES'):.4e},"
+                   f"{avg('SQ_BUSY_CU_CYCLES'):.4e},{avg('GRBM_GUI_ACTIVE'):.4e},"
+                   f"{avg('SQ_VALU_MFMA_BUSY_CYCLES') / (4 * avg('SQ_BUSY_CU_CYCLES')):.3f}")
+    open(f"profiles/{tag}_bench_mfma_util.csv", "w").write("\n".join(out) + "\n")
+    print("\n".join(out[3:]))
