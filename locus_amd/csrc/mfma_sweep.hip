@@ -1,5 +1,6 @@
 // Host side of the matrix-core sweep: per-sweep block packing of X and launch dispatch.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -126,6 +127,12 @@ size_t mfma_lds_bytes(int T)
 
 static int device_cus()
 {
+    // LOCUS_HIP_MFMA_CUS overrides the CU count the launch plan assumes (tests: forces the
+    // multi-launch plan at small d)
+    if (const char* e = getenv("LOCUS_HIP_MFMA_CUS")) {
+        const int v = atoi(e);
+        if (v > 0) return v;
+    }
     static int cus = 0;  // same for every device of a node
     if (cus == 0) {
         int dev = 0;

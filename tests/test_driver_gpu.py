@@ -41,6 +41,24 @@ def test_identity_fixed_iterations(oracle, hip, maxit):
     assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
 
 
+def test_identity_multi_launch_statistics(oracle, hip, monkeypatch):
+    """The fused column statistics across the launches of the planned matrix-core sweep: with
+    one pretended CU the 20 responses go to a T = 2 launch (all 20 <= 32)... so pretend half a
+    tile less: LOCUS_HIP_MFMA_CUS=1 and d = 50 -> 32 (T = 2) + 16 (T = 1) + 2 (T = 1)."""
+    from oracle import ref_driver
+    from locus_amd.locus_core import locus_core_
+    monkeypatch.setenv("LOCUS_HIP_MFMA_CUS", "1")
+    sim, hyper, init, perm_fn = _setup(n=120, p=90, d=50, p0=8, seed=7)
+    kw = dict(tol=1e-30, maxit=3, perm_fn=perm_fn, full_output=True)
+    ref = ref_driver.locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                                 init["sig2_beta_vb"], init["tau_vb"], **kw)
+    got = locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                      init["sig2_beta_vb"], init["tau_vb"], **kw)
+    for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+
+
 def test_identity_to_convergence_recovers_actives(oracle, hip):
     from oracle import ref_driver
     from locus_amd.locus_core import locus_core_

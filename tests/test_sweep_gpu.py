@@ -108,3 +108,16 @@ def test_mfma_sweep_variants(oracle, hip, variant, shape, monkeypatch):
     ref = call_variant(oracle, variant, inp)
     got = call_variant(hip, variant, inp)
     assert_parity(got, ref, what=f"{variant} {shape} mfma")
+
+
+@pytest.mark.parametrize("variant", ["identity", "struct"])
+def test_mfma_planned_multi_launch(oracle, hip, variant, monkeypatch):
+    """The default (planned) mode splits the responses over several launches when they exceed
+    what the CUs hold at once: T = 2 launches of 32 responses per CU, then a T = 1 remainder.
+    Forced at small d by pretending the device has 2 CUs: d = 150 -> 64 + 64 (T = 2) + 22 (T = 1)."""
+    monkeypatch.delenv("LOCUS_HIP_SWEEP_CFG", raising=False)
+    monkeypatch.setenv("LOCUS_HIP_MFMA_CUS", "2")
+    inp = inputs_for(variant, 300, 70, 150, seed=5)
+    ref = call_variant(oracle, variant, inp)
+    got = call_variant(hip, variant, inp)
+    assert_parity(got, ref, what=f"{variant} planned multi-launch")
