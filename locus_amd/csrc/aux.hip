@@ -2,6 +2,7 @@
 // per-sweep prologue, the gamma reductions that update_vb.R / elbo.R need).
 #include "common.h"
 #include "kernels.h"
+#include "fastmath.h"
 
 namespace locus {
 
@@ -172,12 +173,25 @@ __global__ void __launch_bounds__(256) gamma_rows_kernel(const double* __restric
     const int lane = threadIdx.x & 63;
     if (wave >= p) return;
     const double* row = gam + (size_t)wave * d;
-    double s = 0.0, h = 0.0;
-    for (int k = lane; k < d; k += 64) {
-        const double g = row[k];
-        s += g;
-        if (ent) h += g * log(g + eps) + (1.0 - g) * log(1.0 - g + eps);
+    // gam in [0, 1] and eps > 0: both log arguments are positive normal numbers, which is all
+    // log_pos_normal handles (the library log spends half its instructions on special cases)
+    double s0 = 0.0, s1 = 0.0, h0 = 0.0, h1 = 0.0;
+    int k = lane;
+    for (; k + 64 < d; k += 128) {  // two independent element streams per lane
+        const double g0 = row[k], g1 = row[k + 64];
+        s0 += g0;
+        s1 += g1;
+        if (ent) {
+            h0 = fma(g0, log_pos_normal(g0 + eps), fma(1.0 - g0, log_pos_normal(1.0 - g0 + eps), h0));
+            h1 = fma(g1, log_pos_normal(g1 + eps), fma(1.0 - g1, log_pos_normal(1.0 - g1 + eps), h1));
+        }
     }
+    if (k < d) {
+        const double g0 = row[k];
+        s0 += g0;
+        if (ent) h0 = fma(g0, log_pos_normal(g0 + eps), fma(1.0 - g0, log_pos_normal(1.0 - g0 + eps), h0));
+    }
+    double s = s0 + s1, h = h0 + h1;
     for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_xor(s, off);
         h += __shfl_xor(h, off);

@@ -57,6 +57,8 @@ def test_pack_transpose_rows_helpers(hip):
     assert (Xp[:, n:] == 0).all()
     np.testing.assert_allclose(px.xtx.cpu().numpy(), (X * X).sum(axis=0), rtol=1e-14)
     G = rng.random((p, d))
+    G[0, :4] = [0.0, 1.0, 1e-300, 1.0 - 2.0 ** -53]   # ends of the range of gam_vb
+    G[1] = 10.0 ** -rng.uniform(0, 20, size=d)         # tiny inclusion probabilities
     t = dv.transpose(torch.from_numpy(G.T.copy()).to(dev), d, p)     # [d][p] -> [p][d]
     np.testing.assert_array_equal(t.cpu().numpy(), G)
     rs, ent = dv.gamma_rows(t, p, d, eps=2.2e-16)
