@@ -41,6 +41,14 @@ __device__ __forceinline__ double div_1to2(double num, double den)
     return fma(fma(-den, qv, num), rcp, qv);
 }
 
+// 1 / x for positive, finite, normal x with 1 / x normal too: v_rcp_f64 + two Newton steps.
+__device__ __forceinline__ double rcp_pos_normal(double x)
+{
+    double rcp = __builtin_amdgcn_rcp(x);
+    rcp = fma(fma(-x, rcp, 1.0), rcp, rcp);
+    return fma(fma(-x, rcp, 1.0), rcp, rcp);
+}
+
 // log(x) for positive, finite, normal x (no special cases): fdlibm's e_log.c scheme -- x = 2^e m,
 // m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), log m = f - hfsq + s (hfsq + R(s^2)) --
 // with v_frexp_* for the split and div_1to2-style Newton steps for the quotient (2 + f in

@@ -388,7 +388,11 @@ sweep_kernel(const SweepParams P)
                 s2v = s2_ring[u];
                 const double dot = fma(xw_ring[u], bo, U);
                 m = s2v * dot;                                                // coreLoop.cpp:121
-                a = st_lod - P.half_lsi - m * m / (2.0 * s2v) - log(s2v) / 2.0;  // :123-125
+                // :123-125, m^2 / (2 s2) + log(s2) / 2 without the library's division and log:
+                // the latency regime pays 8 issue cycles per instruction (sig2_beta_vb is a
+                // positive normal number)
+                a = st_lod - P.half_lsi - m * m * (0.5 * rcp_pos_normal(s2v)) -
+                    0.5 * log_pos_normal(s2v);
             } else {
                 const double2 k01 = *reinterpret_cast<const double2*>(mycons);
                 const double2 k23 = *reinterpret_cast<const double2*>(mycons + 2);
