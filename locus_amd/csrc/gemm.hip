@@ -7,12 +7,13 @@
 // for which `sqA` squares the A operand on load instead of materialising X^2.
 //
 // Tiling: (32 TW) x (32 TW) block tile, K-tile 16, 4 waves each owning a quadrant as TW x TW MFMA
-// tiles; global loads of the next K-tile are issued before the MFMAs of the current one
-// (register prefetch), LDS rows are padded by 16 doubles so that the two 32-lane halves of a
-// ds_read_b64 fall on disjoint banks.  TW = 2 (64 x 64, several workgroups per CU) is the
-// shipped tile: measured on MI355X it beats TW = 4 (128 x 128, one workgroup per CU, nothing to
-// overlap its LDS fill with) on every product of the path (scripts/perf_gemm.py: 40.7 vs 29.7
-// TFLOP/s on the C3 mat_x_m1).  LOCUS_HIP_GEMM_TW=4 selects the large tile for experiments.
+// tiles.  LDS is double-buffered: ONE barrier per K-tile, tile t + 1 is written to the other buffer
+// while the MFMAs of tile t read this one and tile t + 2 is in flight from global memory (register
+// prefetch through running pointers).  LDS rows are padded by 16 doubles so that the two 32-lane
+// halves of a ds_read_b64 fall on disjoint banks.  TW = 2 (64 x 64; 128 registers, 41 KB of LDS:
+// three workgroups per CU) is the shipped tile: measured on MI355X it beats TW = 4 (128 x 128, one
+// workgroup per CU) on every product of the path (scripts/perf_gemm.py: 44.1 vs 29.1 TFLOP/s on
+// the C3 mat_x_m1).  LOCUS_HIP_GEMM_TW=4 selects the large tile for experiments.
 #include <cstdlib>
 
 #include "common.h"
@@ -29,23 +30,36 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmDesc g)
 {
     constexpr int BM = 32 * TW, BN = 32 * TW;
     constexpr int NQ = BM * BK / 256;  // elements of each operand tile per thread
-    __shared__ double As[BK][BM + LDP];
-    __shared__ double Bs[BK][BN + LDP];
+    __shared__ double As[2][BK][BM + LDP];
+    __shared__ double Bs[2][BK][BN + LDP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
-    // element -> (row-in-tile, k) mapping follows the contiguous dimension of each operand
+    // element -> (row-in-tile, k) mapping follows the contiguous dimension of each operand; per
+    // element: a running pointer, its k index inside a K-tile and whether its row is in range
     const bool a_kfast = (g.sa_k == 1);
     const bool b_kfast = (g.sb_k == 1);
-    int am[NQ], ak[NQ], bn[NQ], bk[NQ];
+    const double* pa[NQ];
+    const double* pb[NQ];
+    int ak[NQ], bk[NQ], al[NQ], bl[NQ];  // k index; LDS offset of the element
+    unsigned okm = 0, okn = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int e = tid + q * 256;
-        if (a_kfast) { ak[q] = e % BK; am[q] = e / BK; } else { am[q] = e % BM; ak[q] = e / BM; }
-        if (b_kfast) { bk[q] = e % BK; bn[q] = e / BK; } else { bn[q] = e % BN; bk[q] = e / BN; }
+        int am, bn;
+        if (a_kfast) { ak[q] = e % BK; am = e / BK; } else { am = e % BM; ak[q] = e / BM; }
+        if (b_kfast) { bk[q] = e % BK; bn = e / BK; } else { bn = e % BN; bk[q] = e / BN; }
+        const bool oa = m0 + am < g.m, ob = n0 + bn < g.n;
+        okm |= (oa ? 1u : 0u) << q;
+        okn |= (ob ? 1u : 0u) << q;
+        pa[q] = g.A + (long)(oa ? m0 + am : 0) * g.sa_m + (long)ak[q] * g.sa_k;
+        pb[q] = g.B + (long)(ob ? n0 + bn : 0) * g.sb_n + (long)bk[q] * g.sb_k;
+        al[q] = ak[q] * (BM + LDP) + am;
+        bl[q] = bk[q] * (BN + LDP) + bn;
     }
+    const long da = (long)BK * g.sa_k, db = (long)BK * g.sb_k;
 
     double4_t acc[TW][TW];
 #pragma unroll
@@ -54,42 +68,53 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmDesc g)
         for (int j = 0; j < TW; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     double ra[NQ], rb[NQ];
-    auto load_tile = [&](int k0) {
+    auto load_tile = [&](int k0) {  // tile starting at k0 -> registers; advances the pointers
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int m = m0 + am[q], k = k0 + ak[q];
-            double v = (m < g.m && k < g.k) ? g.A[(long)m * g.sa_m + (long)k * g.sa_k] : 0.0;
+            const double v = (((okm >> q) & 1u) && k0 + ak[q] < g.k) ? *pa[q] : 0.0;
             ra[q] = g.sqA ? v * v : v;
-            const int n = n0 + bn[q], kb = k0 + bk[q];
-            double u = (n < g.n && kb < g.k) ? g.B[(long)kb * g.sb_k + (long)n * g.sb_n] : 0.0;
+            const double u = (((okn >> q) & 1u) && k0 + bk[q] < g.k) ? *pb[q] : 0.0;
             rb[q] = g.sqB ? u * u : u;
+            pa[q] += da;
+            pb[q] += db;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        double* as = &As[buf][0][0];
+        double* bs = &Bs[buf][0][0];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            as[al[q]] = ra[q];
+            bs[bl[q]] = rb[q];
         }
     };
 
+    // double-buffered LDS: ONE barrier per K-tile; tile t + 1 is written to the other buffer
+    // while the MFMAs of tile t read this one, tile t + 2 is in flight from global memory
     load_tile(0);
+    store_tile(0);
+    if (BK < g.k) load_tile(BK);
+    __syncthreads();
+    int buf = 0;
     for (int k0 = 0; k0 < g.k; k0 += BK) {
-        __syncthreads();  // previous tile fully consumed
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            As[ak[q]][am[q]] = ra[q];
-            Bs[bk[q]][bn[q]] = rb[q];
-        }
-        __syncthreads();
-        if (k0 + BK < g.k) load_tile(k0 + BK);
+        if (k0 + BK < g.k) store_tile(buf ^ 1);
+        if (k0 + 2 * BK < g.k) load_tile(k0 + 2 * BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             const int kr = kk + (lane >> 4);
             double a[TW], b[TW];
 #pragma unroll
-            for (int i = 0; i < TW; ++i) a[i] = As[kr][wm * 16 * TW + i * 16 + (lane & 15)];
+            for (int i = 0; i < TW; ++i) a[i] = As[buf][kr][wm * 16 * TW + i * 16 + (lane & 15)];
 #pragma unroll
-            for (int j = 0; j < TW; ++j) b[j] = Bs[kr][wn * 16 * TW + j * 16 + (lane & 15)];
+            for (int j = 0; j < TW; ++j) b[j] = Bs[buf][kr][wn * 16 * TW + j * 16 + (lane & 15)];
 #pragma unroll
             for (int i = 0; i < TW; ++i)
 #pragma unroll
                 for (int j = 0; j < TW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
+        buf ^= 1;
     }
 
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
