@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--d", type=int, default=10000)
     ap.add_argument("--p0", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--to-tol", type=float, default=0.0,
+                    help="after the timed steps keep iterating until |dELBO| < TOL (R/locus.R:243 uses "
+                         "0.1) and report the secondary metric 'time to ELBO tol' (0 = skip)")
     ap.add_argument("--cpu-covariates", type=int, default=0,
                     help="covariates of the CPU sample (0 = sized for ~15 s)")
     return ap.parse_args()
@@ -210,6 +213,21 @@ def main():
         dt = float(tt.item())
     kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev])) if ev else float("nan")
 
+    # secondary metric of BASELINE.json: wall time from the default initial values to |dELBO| < tol
+    # = all iterations so far (at the measured step time) + the ones still needed, timed here
+    to_tol = None
+    if args.to_tol > 0:
+        n_before = len(lbs)
+        t1 = time.perf_counter()
+        while len(lbs) < 500 and (len(lbs) < 2 or abs(lbs[-1] - lbs[-2]) >= args.to_tol):
+            lbs.append(step())
+        torch.cuda.synchronize()
+        comm.barrier()
+        extra = time.perf_counter() - t1
+        to_tol = {"tol": args.to_tol, "iterations": len(lbs),
+                  "converged": bool(abs(lbs[-1] - lbs[-2]) < args.to_tol),
+                  "seconds": n_before * dt / args.steps + extra}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = p * d / (dt / args.steps)
@@ -241,6 +259,8 @@ def main():
                               "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
                               "flops_per_update": flops_per_update},
         }
+        if to_tol is not None:
+            out["time_to_elbo_tol"] = to_tol
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_covariates)
         print(json.dumps(out), flush=True)
