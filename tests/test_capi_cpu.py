@@ -90,3 +90,19 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "liblocus_oracle" not in txt, f
+
+
+def test_workspace_bytes_cover_the_matrix_core_streams():
+    """locus_hip_sweep_workspace_bytes(n, p) must hold the block-packed operand streams of the
+    matrix-core sweep: (p / 16 + 2) iterations x padded rows x 32 doubles (both operand forms),
+    for the larger of the T = 1 (6 waves) and T = 2 (7 waves) row paddings."""
+    from locus_amd import _lib
+    f = _lib.lib().locus_hip_sweep_workspace_bytes
+    for n, p in [(200, 500), (1000, 50000), (1008, 16), (2016, 1000), (1, 1)]:
+        nit = (p + 15) // 16 + 2
+        tiles = (n + 15) // 16
+        rows = 16 * max(6 * -(-tiles // 6), 7 * -(-tiles // 7) if n <= 1008 else 0)
+        assert f(n, p) >= 8 * nit * rows * 32, (n, p)
+    assert f(1000, 50000) > f(1000, 25000) > f(1000, 16)
+    # n beyond the matrix-core kernel: only the step records remain
+    assert f(4000, 50000) < 64 * 50000
