@@ -5,7 +5,8 @@ Layout:
   _lib.py          ctypes bindings of the C ABI (no fallback: fails without the .so / GPU)
   core.py          coreLoop, coreBatch, ... : the reference's eight native routines
   device.py        device-resident state and kernels for the drivers
-  update_vb.py, elbo.py, locus_core.py, ...   host side of the drivers (mirrors R/)
+  update_vb.py, elbo.py, locus_core.py, locus_z_core.py, locus_struct_core.py,
+  locus_bin_core.py   host side of the drivers (mirrors R/)
 """
 from . import _lib  # noqa: F401
 from .core import (coreBatch, coreLogitLoop, coreLoop, coreProbitBatch,  # noqa: F401

@@ -98,6 +98,36 @@ class IdentityHost(HostBase):
         a_vb, b_vb = self.a_vb, self.b_vb
         return a_vb / (a_vb + b_vb)
 
+    def _omega_terms(self):
+        """Covariate-wise terms of the ELBO at c = 1 (R/locus_core.R:270-275; R/elbo.R:43-54,
+        114-118), evaluated where rowSums(gam) lives; two scalars come back:
+        sum_j rs_gam log om + (d - rs_gam) log(1 - om)  and  e_omega_."""
+        import torch
+        d = self.d
+        rs, a, b = self.rs_gam_t, self.a_t, self.b_t
+        a_vb = a + rs                                    # update_a_vb / update_b_vb with c = 1
+        b_vb = b - rs + d
+        dg = torch.digamma(a_vb + b_vb)
+        log_om_vb = torch.digamma(a_vb) - dg
+        log_1_min_om_vb = torch.digamma(b_vb) - dg
+        lbeta = lambda x, y: torch.lgamma(x) + torch.lgamma(y) - torch.lgamma(x + y)  # noqa: E731
+        s_bg = (rs * log_om_vb).sum() + ((d - rs) * log_1_min_om_vb).sum()
+        e_om = ((a - a_vb) * log_om_vb + (b - b_vb) * log_1_min_om_vb - lbeta(a, b)
+                + lbeta(a_vb, b_vb)).sum()
+        s_bg, e_om = torch.stack([s_bg, e_om]).cpu().numpy()
+        return float(s_bg), float(e_om)
+
+    def _log_om_terms(self, c):
+        """log_om_vb, log_1_min_om_vb (R/update_vb.R:187,190) on the device of rowSums(gam)."""
+        import torch
+        d = self.d
+        if c not in self._digam_sum:
+            self._digam_sum = {c: torch.digamma(c * (self.a_t + self.b_t + d) - 2 * c + 2)}
+        digam_sum = self._digam_sum[c]
+        rs = self.rs_gam_t
+        return (torch.digamma(c * (self.a_t + rs) - c + 1) - digam_sum,
+                torch.digamma(c * (self.b_t - rs + d) - c + 1) - digam_sum)
+
     def set_initial(self, stats, rs_gam_local):
         """R/locus_core.R:36-42: statistics of the initial gam_vb / mu_beta_vb."""
         self.stats = np.asarray(stats, dtype=np.float64)
@@ -108,11 +138,7 @@ class IdentityHost(HostBase):
     # -- top of the iteration: R/locus_core.R:57-84 ----------------------------
     def begin_iteration(self, c=1.0):
         n, d = self.n, self.d
-        import torch
         cs_gam, cs_m2, cs_b2, rss = self.stats
-        if c not in self._digam_sum:
-            self._digam_sum = {c: torch.digamma(c * (self.a_t + self.b_t + d) - 2 * c + 2)}
-        digam_sum = self._digam_sum[c]
         lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam, c)
         nu_vb = U.update_nu_vb_(self.nu, self.sum_tau_m2, c)
         self.sig2_inv_vb = lambda_vb / nu_vb
@@ -122,10 +148,7 @@ class IdentityHost(HostBase):
         self.sig2_beta_vb = U.update_sig2_beta_vb_(n, self.sig2_inv_vb, self.tau_vb, c)
         log_tau_vb = U.update_log_tau_vb_(eta_vb, kappa_vb)
         log_sig2_inv_vb = U.update_log_sig2_inv_vb_(lambda_vb, nu_vb)
-        # R/update_vb.R:187,190 on the device that holds rowSums(gam)
-        rs = self.rs_gam_t
-        log_om_vb = torch.digamma(c * (self.a_t + rs) - c + 1) - digam_sum
-        log_1_min_om_vb = torch.digamma(c * (self.b_t - rs + d) - c + 1) - digam_sum
+        log_om_vb, log_1_min_om_vb = self._log_om_terms(c)
         s2 = self.sig2_beta_vb
         return dict(
             lo=log_om_vb, l1=log_1_min_om_vb, log_sig2_inv_vb=float(log_sig2_inv_vb),
@@ -155,19 +178,7 @@ class IdentityHost(HostBase):
         self._c_last = c
         if not with_elbo:
             return None
-        # covariate-wise terms of elbo_ (R/locus_core.R:270-275; R/elbo.R:43-54, 114-118) where
-        # rowSums(gam) lives; two scalars come back
-        rs, a, b = self.rs_gam_t, self.a_t, self.b_t
-        a_vb = a + rs                                    # update_a_vb / update_b_vb with c = 1
-        b_vb = b - rs + d
-        dg = torch.digamma(a_vb + b_vb)
-        log_om_vb = torch.digamma(a_vb) - dg
-        log_1_min_om_vb = torch.digamma(b_vb) - dg
-        lbeta = lambda x, y: torch.lgamma(x) + torch.lgamma(y) - torch.lgamma(x + y)
-        s_bg = (rs * log_om_vb).sum() + ((d - rs) * log_1_min_om_vb).sum()
-        e_om = ((a - a_vb) * log_om_vb + (b - b_vb) * log_1_min_om_vb - lbeta(a, b)
-                + lbeta(a_vb, b_vb)).sum()
-        s_bg, e_om = torch.stack([s_bg, e_om]).cpu().numpy()
+        s_bg, e_om = self._omega_terms()
         lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam)
         nu_vb = U.update_nu_vb_(self.nu, self.sum_tau_m2)
         log_sig2_inv_vb = digamma(lambda_vb) - np.log(nu_vb)

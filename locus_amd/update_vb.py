@@ -67,6 +67,10 @@ def update_log_tau_vb_(eta_vb, kappa_vb):  # :275
     return digamma(eta_vb) - np.log(kappa_vb)
 
 
+def update_m2_alpha_(alpha_vb, sig2_alpha_vb):  # :18-29 (sig2_alpha_vb of alpha_vb's shape)
+    return sig2_alpha_vb + alpha_vb ** 2
+
+
 def update_phi_z_vb_(phi, d, c=1.0):  # :407
     return c * (phi + d / 2) - c + 1
 

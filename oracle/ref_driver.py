@@ -778,6 +778,169 @@ def locus_probit_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_a
 
 
 # --------------------------------------------------------------------------- #
+# R/locus_z_core.R (identity link with fixed covariates Z)
+# --------------------------------------------------------------------------- #
+def update_sig2_alpha_z_vb_(n, zeta2_inv_vb, tau_vb, c=1.0):  # R/update_vb.R:32-49 (tau given)
+    den = n - 1 + np.asarray(zeta2_inv_vb, dtype=np.float64)
+    return 1 / (c * np.outer(den, tau_vb))
+
+
+def update_eta_z_vb_(n, q, eta, gam_vb, c=1.0):  # R/update_vb.R:226
+    return c * (eta + n / 2 + gam_vb.sum(axis=0) / 2 + q / 2) - c + 1
+
+
+def update_kappa_z_vb_(Y, kappa, alpha_vb, beta_vb, m2_alpha, m2_beta, mat_x_m1, mat_z_mu,
+                       sig2_inv_vb, zeta2_inv_vb, c=1.0):  # R/update_vb.R:255-272
+    n = Y.shape[0]
+    return c * (kappa + ((Y ** 2).sum(axis=0) - 2 * (Y * (mat_x_m1 + mat_z_mu)).sum(axis=0)
+                         + (n - 1 + sig2_inv_vb) * m2_beta.sum(axis=0)
+                         + (mat_x_m1 ** 2).sum(axis=0) - (n - 1) * (beta_vb ** 2).sum(axis=0)
+                         + (n - 1) * m2_alpha.sum(axis=0) + m2_alpha.T @ zeta2_inv_vb
+                         + (mat_z_mu ** 2).sum(axis=0) - (n - 1) * (alpha_vb ** 2).sum(axis=0)
+                         + 2 * (mat_x_m1 * mat_z_mu).sum(axis=0)) / 2)
+
+
+def update_xi_z_vb_(xi, tau_vb, m2_alpha, c=1.0):  # R/update_vb.R:410
+    return c * (xi + m2_alpha @ tau_vb / 2)
+
+
+def e_alpha_(m2_alpha, log_tau_vb, log_zeta2_inv_vb, sig2_alpha_vb, tau_vb, zeta2_inv_vb):
+    """R/elbo.R:11-19."""
+    return 1 / 2 * np.sum(-(m2_alpha * tau_vb[None, :]) * zeta2_inv_vb[:, None]
+                          + log_tau_vb[None, :] + log_zeta2_inv_vb[:, None]
+                          + np.log(sig2_alpha_vb) + 1)
+
+
+def elbo_z_(Y, Z, a, a_vb, b, b_vb, beta_vb, eta, gam_vb, kappa, lam, alpha_vb, nu, phi, phi_vb,
+            sig2_alpha_vb, sig2_beta_vb, sig2_inv_vb, tau_vb, xi, zeta2_inv_vb, m2_alpha, m2_beta,
+            mat_x_m1, mat_z_mu, sum_gam):
+    """R/locus_z_core.R:299-342."""
+    n, q = Y.shape[0], Z.shape[1]
+    xi_vb = update_xi_z_vb_(xi, tau_vb, m2_alpha)
+    eta_vb = update_eta_z_vb_(n, q, eta, gam_vb)
+    kappa_vb = update_kappa_z_vb_(Y, kappa, alpha_vb, beta_vb, m2_alpha, m2_beta, mat_x_m1,
+                                  mat_z_mu, sig2_inv_vb, zeta2_inv_vb)
+    lambda_vb = update_lambda_vb_(lam, sum_gam)
+    nu_vb = update_nu_vb_(nu, m2_beta, tau_vb)
+    log_tau_vb = digamma(eta_vb) - np.log(kappa_vb)
+    log_zeta2_inv_vb = digamma(phi_vb) - np.log(xi_vb)
+    log_sig2_inv_vb = digamma(lambda_vb) - np.log(nu_vb)
+    log_om_vb = digamma(a_vb) - digamma(a_vb + b_vb)
+    log_1_min_om_vb = digamma(b_vb) - digamma(a_vb + b_vb)
+    elbo_A = (e_y_(n, kappa, kappa_vb, log_tau_vb, m2_beta, sig2_inv_vb, tau_vb)
+              + np.sum(tau_vb * (m2_alpha.T @ zeta2_inv_vb) / 2))       # R/elbo.R:195-196
+    elbo_B = e_beta_gamma_(gam_vb, log_om_vb, log_1_min_om_vb, log_sig2_inv_vb, log_tau_vb,
+                           m2_beta, sig2_beta_vb, sig2_inv_vb, tau_vb)
+    elbo_C = e_tau_(eta, eta_vb, kappa, kappa_vb, log_tau_vb, tau_vb)
+    elbo_D = e_sig2_inv_(lam, lambda_vb, log_sig2_inv_vb, nu, nu_vb, sig2_inv_vb)
+    elbo_E = e_omega_(a, a_vb, b, b_vb, log_om_vb, log_1_min_om_vb)
+    elbo_F = e_alpha_(m2_alpha, log_tau_vb, log_zeta2_inv_vb, sig2_alpha_vb, tau_vb,
+                      zeta2_inv_vb)
+    elbo_G = e_zeta2_inv_(log_zeta2_inv_vb, phi, phi_vb, xi, xi_vb, zeta2_inv_vb)
+    return elbo_A + elbo_B + elbo_C + elbo_D + elbo_E + elbo_F + elbo_G
+
+
+def locus_z_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
+                  sig2_beta_vb, tau_vb, tol, maxit, perm_fn, alpha_perm_fn=None, anneal=None,
+                  debug=True, trace=None):
+    """R/locus_z_core.R:8-290, scheme batch = "y".  Y centred, X and Z standardised."""
+    Y = np.asfortranarray(Y, dtype=np.float64)
+    X = np.asfortranarray(X, dtype=np.float64)
+    Z = np.asfortranarray(Z, dtype=np.float64)
+    n, d = Y.shape
+    p, q = X.shape[1], Z.shape[1]
+    a, b = list_hyper["a"], list_hyper["b"]
+    eta, kappa = list_hyper["eta"], list_hyper["kappa"]
+    lam, nu = list_hyper["lambda"], list_hyper["nu"]
+    phi = np.atleast_1d(np.asarray(list_hyper["phi"], dtype=np.float64))
+    xi = np.atleast_1d(np.asarray(list_hyper["xi"], dtype=np.float64))
+    gam_vb = np.asfortranarray(gam_vb, dtype=np.float64).copy(order="F")
+    mu_beta_vb = np.asfortranarray(mu_beta_vb, dtype=np.float64).copy(order="F")
+    alpha_vb = np.array(alpha_vb, dtype=np.float64).reshape(q, d)
+    sig2_alpha_vb = np.array(sig2_alpha_vb, dtype=np.float64).reshape(q, d)
+    sig2_beta_vb = np.array(sig2_beta_vb, dtype=np.float64)
+    tau_vb = np.array(tau_vb, dtype=np.float64)
+
+    if anneal is None:
+        annealing, c, ladder = False, 1.0, None
+    else:
+        annealing, ladder = True, get_annealing_ladder_(anneal)
+        c = float(ladder[0])
+
+    m2_alpha = update_m2_alpha_(alpha_vb, sig2_alpha_vb)                # :32
+    beta_vb = update_beta_vb_(gam_vb, mu_beta_vb)
+    m2_beta = update_m2_beta_(gam_vb, mu_beta_vb, sig2_beta_vb, sweep=True)
+    mat_x_m1 = np.asfortranarray(X @ beta_vb)
+    mat_z_mu = np.asfortranarray(Z @ alpha_vb)
+    rs_gam = gam_vb.sum(axis=1)
+    sum_gam = rs_gam.sum()
+    converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
+    om_vb = None
+
+    while (not converged) and it < maxit:                               # :49
+        lb_old = lb_new
+        it += 1
+        digam_sum = digamma(c * (a + b + d) - 2 * c + 2)
+        phi_vb = update_phi_z_vb_(phi, d, c)                            # :60-63
+        xi_vb = update_xi_z_vb_(xi, tau_vb, m2_alpha, c)
+        zeta2_inv_vb = phi_vb / xi_vb
+        lambda_vb = update_lambda_vb_(lam, sum_gam, c)                  # :67-70
+        nu_vb = update_nu_vb_(nu, m2_beta, tau_vb, c)
+        sig2_inv_vb = lambda_vb / nu_vb
+        eta_vb = update_eta_z_vb_(n, q, eta, gam_vb, c)                 # :74-79
+        kappa_vb = update_kappa_z_vb_(Y, kappa, alpha_vb, beta_vb, m2_alpha, m2_beta, mat_x_m1,
+                                      mat_z_mu, sig2_inv_vb, zeta2_inv_vb, c)
+        tau_vb = eta_vb / kappa_vb
+        sig2_alpha_vb = update_sig2_alpha_z_vb_(n, zeta2_inv_vb, tau_vb, c)   # :82-83
+        sig2_beta_vb = update_sig2_beta_vb_(n, sig2_inv_vb, tau_vb, c)
+        log_tau_vb = update_log_tau_vb_(eta_vb, kappa_vb)
+        log_sig2_inv_vb = update_log_sig2_inv_vb_(lambda_vb, nu_vb)
+        log_om_vb = update_log_om_vb(a, digam_sum, rs_gam, c)           # :93-94
+        log_1_min_om_vb = update_log_1_min_om_vb(b, d, digam_sum, rs_gam, c)
+
+        order = range(q) if alpha_perm_fn is None else alpha_perm_fn(it)
+        for i in order:                                                 # :96-103
+            mat_z_mu = mat_z_mu - np.outer(Z[:, i], alpha_vb[i, :])
+            alpha_vb[i, :] = c * sig2_alpha_vb[i, :] * (tau_vb * ((Y - mat_z_mu - mat_x_m1).T
+                                                                  @ Z[:, i]))
+            mat_z_mu = mat_z_mu + np.outer(Z[:, i], alpha_vb[i, :])
+        mat_z_mu = np.asfortranarray(mat_z_mu)
+
+        shuffled_ind = np.ascontiguousarray(perm_fn(it), dtype=np.float64)
+        c_oracle.coreZLoop(X, Y, gam_vb, log_om_vb, log_1_min_om_vb, log_sig2_inv_vb,
+                           log_tau_vb, beta_vb, mat_x_m1, mat_z_mu, mu_beta_vb, sig2_beta_vb,
+                           tau_vb, shuffled_ind, c)                     # :108-110
+        rs_gam = gam_vb.sum(axis=1)
+
+        m2_alpha = update_m2_alpha_(alpha_vb, sig2_alpha_vb)            # :204-205
+        m2_beta = update_m2_beta_(gam_vb, mu_beta_vb, sig2_beta_vb, sweep=True)
+        a_vb = update_a_vb(a, rs_gam, c)
+        b_vb = update_b_vb(b, d, rs_gam, c)
+        om_vb = a_vb / (a_vb + b_vb)
+        sum_gam = rs_gam.sum()
+
+        if annealing:                                                   # :214-228
+            c = float(ladder[it]) if it < len(ladder) else 1.0
+            if np.isclose(c, 1.0, rtol=1.5e-8, atol=0):
+                annealing = False
+        else:
+            lb_new = elbo_z_(Y, Z, a, a_vb, b, b_vb, beta_vb, eta, gam_vb, kappa, lam, alpha_vb,
+                             nu, phi, phi_vb, sig2_alpha_vb, sig2_beta_vb, sig2_inv_vb, tau_vb,
+                             xi, zeta2_inv_vb, m2_alpha, m2_beta, mat_x_m1, mat_z_mu, sum_gam)
+            if trace is not None:
+                trace.append((it, float(lb_new)))
+            if debug and lb_new + EPS_SQRT < lb_old:                    # :238-239
+                raise RuntimeError("ELBO not increasing monotonically. Exit. ")
+            converged = abs(lb_new - lb_old) < tol
+
+    return dict(beta_vb=beta_vb, gam_vb=gam_vb, om_vb=om_vb, alpha_vb=alpha_vb,
+                converged=converged, it=it, lb_opt=lb_new, diff_lb=abs(lb_new - lb_old),
+                mu_beta_vb=mu_beta_vb, mat_x_m1=mat_x_m1, mat_z_mu=mat_z_mu,
+                sig2_alpha_vb=sig2_alpha_vb, sig2_beta_vb=sig2_beta_vb, tau_vb=tau_vb,
+                zeta2_inv_vb=zeta2_inv_vb, sig2_inv_vb=sig2_inv_vb)
+
+
+# --------------------------------------------------------------------------- #
 # Second, independent restatement of one sweep -- used only to cross-check the C
 # oracle.  It is taken from the scalar R formulas of the "batch 0" scheme
 # (R/locus_core.R:144-155), i.e. a different operand association from the C++

@@ -59,6 +59,35 @@ def test_identity_multi_launch_statistics(oracle, hip, monkeypatch):
     assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
 
 
+@pytest.mark.parametrize("anneal", [None, (1, 2.0, 3)])
+def test_z_covariates_driver(oracle, hip, anneal):
+    """locus_z_core_ (R/locus_z_core.R): identity link with q = 3 fixed covariates, against the
+    numpy restatement; 5 iterations, identical sweep and alpha orders."""
+    from oracle import ref_driver
+    from locus_amd.locus_z_core import locus_z_core_
+    sim, hyper, init, perm_fn = _setup(n=150, p=300, d=37, p0=10, seed=11)
+    n, d, q = 150, 37, 3
+    rng = np.random.default_rng(2)
+    Z = rng.normal(size=(n, q))
+    Z = np.asfortranarray((Z - Z.mean(axis=0)) / Z.std(axis=0, ddof=1))
+    hyper["phi"], hyper["xi"] = np.ones(q), np.array([1.0, 0.5, 2.0])
+    alpha0 = rng.normal(scale=0.2, size=(q, d))
+    s2a0 = rng.gamma(2.0, 0.3, size=(q, d))
+    aperms = [np.random.default_rng(40 + i).permutation(q) for i in range(8)]
+    kw = dict(tol=1e-30, maxit=5, perm_fn=perm_fn, alpha_perm_fn=lambda it: aperms[it],
+              anneal=anneal)
+    args = (sim["Y"], sim["X"], Z, hyper, init["gam_vb"], alpha0, init["mu_beta_vb"], s2a0,
+            init["sig2_beta_vb"], init["tau_vb"])
+    ref = ref_driver.locus_z_core_(*args, **kw)
+    got = locus_z_core_(*args, full_output=True, **kw)
+    assert got["it"] == ref["it"] == 5
+    for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1", "alpha_vb", "mat_z_mu",
+              "sig2_alpha_vb", "tau_vb"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+    assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+
+
 def test_identity_to_convergence_recovers_actives(oracle, hip):
     from oracle import ref_driver
     from locus_amd.locus_core import locus_core_

@@ -24,7 +24,7 @@ for pth in (ROOT, HERE):
 
 N, P, D, P0 = 60, 80, 7, 6
 MAXIT = 3
-KINDS = ["identity", "anneal", "struct", "logit", "probit"]
+KINDS = ["identity", "anneal", "struct", "logit", "probit", "z", "z-anneal"]
 
 
 def _problem(kind):
@@ -48,6 +48,17 @@ def _problem(kind):
         init["alpha_vb"] = rng.normal(scale=0.1, size=(2, D))
         init["sig2_alpha_vb"] = (np.array([1.0, 0.5]) if link == "probit"
                                  else rng.gamma(2.0, 0.2, size=(2, D)))
+    if kind in ("z", "z-anneal"):
+        rng = np.random.default_rng(4)
+        Zc = rng.normal(size=(N, 3))
+        extra["Z"] = np.asfortranarray((Zc - Zc.mean(axis=0)) / Zc.std(axis=0, ddof=1))
+        hyper["phi"] = np.array([1.0, 1.0, 2.0])
+        hyper["xi"] = np.array([1.0, 0.5, 1.0])
+        init["alpha_vb"] = rng.normal(scale=0.2, size=(3, D))
+        init["sig2_alpha_vb"] = rng.gamma(2.0, 0.3, size=(3, D))
+        perms = [np.random.default_rng(50 + i).permutation(P).astype(np.float64) for i in range(16)]
+        aperms = [np.random.default_rng(90 + i).permutation(3) for i in range(16)]
+        return sim, hyper, init, extra, (lambda it: perms[it]), (lambda it: aperms[it])
     if kind == "struct":
         extra["ls"] = set_struct(N, P, np.arange(1, P + 1, 20))
     perms = [np.random.default_rng(50 + i).permutation(P).astype(np.float64) for i in range(16)]
@@ -61,6 +72,17 @@ def _run(kind, which, comm=None):
     sim, hyper, init, extra, perm_fn, aperm_fn = _problem(kind)
     Y, X = sim["Y"], sim["X"]
     common = dict(tol=1e-30, maxit=MAXIT, perm_fn=perm_fn)
+    if kind in ("z", "z-anneal"):
+        an = (1, 2.0, 2) if kind == "z-anneal" else None
+        args = (Y, X, extra["Z"], hyper, init["gam_vb"], init["alpha_vb"], init["mu_beta_vb"],
+                init["sig2_alpha_vb"], init["sig2_beta_vb"], init["tau_vb"])
+        if which == "ref":
+            from oracle import ref_driver as R
+            return R.locus_z_core_(*args, anneal=an, alpha_perm_fn=aperm_fn, **common)
+        import cpu_device
+        from locus_amd.locus_z_core import locus_z_core_
+        return locus_z_core_(*args, anneal=an, alpha_perm_fn=aperm_fn, comm=comm,
+                             full_output=True, _test_backend=cpu_device, **common)
     if which == "ref":
         from oracle import ref_driver as R
         if kind in ("identity", "anneal"):
@@ -93,7 +115,7 @@ def _run(kind, which, comm=None):
 def _compare(kind, got, ref):
     assert got["it"] == ref["it"] == MAXIT
     keys = ["gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1"]
-    if kind in ("logit", "probit"):
+    if kind in ("logit", "probit", "z", "z-anneal"):
         keys += ["alpha_vb", "mat_z_mu"]
     for k in keys:
         np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=f"{kind} {k}")
