@@ -3,6 +3,7 @@
 Layout:
   csrc/            HIP kernels + the C ABI (include/locus_hip.h) -> liblocus_hip.so
   _lib.py          ctypes bindings of the C ABI (no fallback: fails without the .so / GPU)
+  locus.py         locus(Y, X, p0_av, ...): the user-level entry (R/locus.R)
   core.py          coreLoop, coreBatch, ... : the reference's eight native routines
   device.py        device-resident state and kernels for the drivers
   update_vb.py, elbo.py, locus_core.py, locus_z_core.py, locus_struct_core.py,
@@ -12,5 +13,7 @@ from . import _lib  # noqa: F401
 from .core import (coreBatch, coreLogitLoop, coreLoop, coreProbitBatch,  # noqa: F401
                    coreProbitLoop, coreStructLoop, coreZBatch, coreZLoop)
 
-__all__ = ["coreLoop", "coreZLoop", "coreLogitLoop", "coreProbitLoop", "coreStructLoop",
+from .locus import locus  # noqa: F401,E402
+
+__all__ = ["locus", "coreLoop", "coreZLoop", "coreLogitLoop", "coreProbitLoop", "coreStructLoop",
            "coreBatch", "coreZBatch", "coreProbitBatch"]

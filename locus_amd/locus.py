@@ -1,0 +1,92 @@
+"""locus(Y, X, p0_av, ...): the user-level entry of the reference (R/locus.R:240-640), for the
+paths rebuilt here.  Prepares the data (standardisation, constant / duplicated columns), sets the
+default hyper-parameters and initial values when none are given, dispatches on link / Z /
+list_struct to the device-resident drivers and returns the reference's `vb` fields.
+
+Not rebuilt (out of scope): cross-validation (list_cv), the block fan-out
+(list_blocks), group selection (list_groups) and the mixed identity / probit model (ind_bin);
+asking for them raises NotImplementedError rather than silently doing something else.
+"""
+import numpy as np
+
+from .prepare import (add_intercept_, auto_set_hyper_, auto_set_init_, convert_p0_av_,
+                      prepare_data_, scale_rm_)
+
+
+def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, list_init=None,
+          list_cv=None, list_blocks=None, list_groups=None, list_struct=None, user_seed=None,
+          tol=0.1, maxit=1000, anneal=None, full_output=False, verbose=True,
+          checkpoint_path=None, comm=None, device=None, _test_backend=None):
+    """Arguments and return fields as R/locus.R:240-245, :605-640 (`comm`: response sharding over
+    the GPUs of a node, see locus_amd.comm; every rank passes the full arrays)."""
+    for name, v in (("list_cv", list_cv), ("list_blocks", list_blocks),
+                    ("list_groups", list_groups), ("ind_bin", ind_bin)):
+        if v is not None:
+            raise NotImplementedError(f"{name} is outside the rebuilt path (SURVEY.md §8)")
+    if link not in ("identity", "logit", "probit"):
+        raise NotImplementedError(f"link = {link!r} is outside the rebuilt path")
+    # check_annealing_ (R/utils.R:47-68): annealing only for the identity link without structure
+    if anneal is not None and (link != "identity" or list_struct is not None):
+        raise ValueError("Annealing has been implemented only for the identity link, "
+                         "without structured sparsity")
+    if list_struct is not None and (link != "identity" or Z is not None):
+        raise ValueError("list_struct requires link = 'identity' and Z = NULL")  # set_hyper:211
+
+    if verbose:
+        print("== Preparing the data ... ")
+    Y, X, bool_rmvd_x = prepare_data_(Y, X, link)
+    n, d = Y.shape
+    p = X.shape[1]
+    q = bool_rmvd_z = None
+    if Z is not None:                                            # R/prepare_locus.R:69-101
+        Z = np.asarray(Z, dtype=np.float64)
+        if Z.shape[0] != n:
+            raise ValueError("Z must have the same number of samples as Y and X.")
+        Z, bool_rmvd_z = scale_rm_(Z)
+        Z = np.asfortranarray(Z)
+        q = Z.shape[1]
+    if list_struct is not None:                                  # prepare_struct_: drop removed SNPs
+        list_struct = dict(list_struct)
+        list_struct["vec_fac_st"] = np.asarray(list_struct["vec_fac_st"])[~bool_rmvd_x]
+
+    p_star = None
+    if list_hyper is None or list_init is None:
+        p_star = convert_p0_av_(p0_av, len(bool_rmvd_x))
+        if np.ndim(p_star) > 0:
+            p_star = p_star[~bool_rmvd_x]
+    if list_hyper is None:
+        list_hyper = auto_set_hyper_(Y, p, p_star, q=q, link=link, struct=list_struct is not None)
+    else:
+        list_hyper = dict(list_hyper)
+    if list_init is None:
+        list_init = auto_set_init_(Y, p, p_star, q=q, user_seed=user_seed, link=link)
+    else:
+        list_init = dict(list_init)
+    if link != "identity":
+        Z = add_intercept_(n, d, list_hyper, list_init, link, Z)
+
+    kw = dict(tol=tol, maxit=maxit, verbose=verbose, full_output=full_output, comm=comm,
+              device=device, _test_backend=_test_backend)
+    li = list_init
+    if link == "identity" and list_struct is not None:
+        from .locus_struct_core import locus_struct_core_
+        vb = locus_struct_core_(Y, X, list_hyper, li["gam_vb"], li["mu_beta_vb"],
+                                li["sig2_beta_vb"], li["tau_vb"], list_struct, **kw)
+    elif link == "identity" and Z is None:
+        from .locus_core import locus_core_
+        vb = locus_core_(Y, X, list_hyper, li["gam_vb"], li["mu_beta_vb"], li["sig2_beta_vb"],
+                         li["tau_vb"], anneal=anneal, checkpoint_path=checkpoint_path, **kw)
+    elif link == "identity":
+        from .locus_z_core import locus_z_core_
+        vb = locus_z_core_(Y, X, Z, list_hyper, li["gam_vb"], li["alpha_vb"], li["mu_beta_vb"],
+                           li["sig2_alpha_vb"], li["sig2_beta_vb"], li["tau_vb"], anneal=anneal,
+                           **kw)
+    else:
+        from . import locus_bin_core
+        fn = getattr(locus_bin_core, f"locus_{link}_core_")
+        vb = fn(Y, X, Z, list_hyper, li["gam_vb"], li["alpha_vb"], li["mu_beta_vb"],
+                li["sig2_alpha_vb"], li["sig2_beta_vb"], **kw)
+    vb["p_star"] = p_star
+    vb["rmvd_x"] = np.nonzero(bool_rmvd_x)[0]                    # R/locus.R:620-626
+    vb["rmvd_z"] = None if bool_rmvd_z is None else np.nonzero(bool_rmvd_z)[0]
+    return vb

@@ -8,21 +8,28 @@ import numpy as np
 from scipy.stats import norm
 
 
-def prepare_data_(Y, X, link="identity"):
-    """R/prepare_locus.R:109-141: scale(X) (centre, sd with n-1), drop constant and duplicated
-    columns, centre Y (identity) / subtract 1/2 (logit).  Returns (Y, X, bool_rmvd_x)."""
+def scale_rm_(X):
+    """scale(X) (centre, sd with n - 1), then rm_constant_ and rm_collinear_ (R/utils.R:244-311):
+    returns the kept columns and the mask of the removed ones."""
     X = np.asarray(X, dtype=np.float64)
-    Y = np.asarray(Y, dtype=np.float64)
     with np.errstate(invalid="ignore", divide="ignore"):
         Xs = (X - X.mean(axis=0)) / X.std(axis=0, ddof=1)
-    bool_cst = np.isnan(Xs.sum(axis=0))                       # rm_constant_, R/utils.R:244-271
+    bool_cst = np.isnan(Xs.sum(axis=0))                       # rm_constant_
     Xs = Xs[:, ~bool_cst]
-    _, first = np.unique(Xs, axis=1, return_index=True)       # rm_collinear_, R/utils.R:273-311
+    _, first = np.unique(Xs, axis=1, return_index=True)       # rm_collinear_: keep first copies
     bool_coll = np.ones(Xs.shape[1], dtype=bool)
     bool_coll[first] = False
     Xs = Xs[:, ~bool_coll]
-    bool_rmvd_x = bool_cst.copy()
-    bool_rmvd_x[~bool_cst] = bool_coll
+    bool_rmvd = bool_cst.copy()
+    bool_rmvd[~bool_cst] = bool_coll
+    return Xs, bool_rmvd
+
+
+def prepare_data_(Y, X, link="identity"):
+    """R/prepare_locus.R:109-141: scale(X) (centre, sd with n-1), drop constant and duplicated
+    columns, centre Y (identity) / subtract 1/2 (logit).  Returns (Y, X, bool_rmvd_x)."""
+    Y = np.asarray(Y, dtype=np.float64)
+    Xs, bool_rmvd_x = scale_rm_(X)
     if Xs.shape[1] < 1:
         raise ValueError("There must be at least 1 non-constant candidate predictor stored in X.")
     if link == "identity":
@@ -110,15 +117,35 @@ def auto_set_init_(Y, p, p_star, q=None, user_seed=None, link="identity"):
     else:  # probit
         init["tau_vb"] = None
         init["sig2_beta_vb"] = float(1.0 / rng.gamma(2.0, sig2_inv_vb))
-    init["alpha_vb"] = init["sig2_alpha_vb"] = None
+    if q is not None:                                        # R/set_hyper_init.R:823-848
+        init["alpha_vb"] = rng.normal(size=(q, d))
+        if link == "identity":
+            zeta2_inv_vb = rng.gamma(1.0, 1.0, size=q)
+            init["sig2_alpha_vb"] = 1.0 / rng.gamma(2.0, np.outer(zeta2_inv_vb, init["tau_vb"]))
+        elif link == "logit":
+            init["sig2_alpha_vb"] = 1.0 / rng.gamma(2.0, rng.gamma(1.0, 1.0, size=(q, d)))
+        else:
+            init["sig2_alpha_vb"] = 1.0 / rng.gamma(2.0, rng.gamma(1.0, 1.0, size=q))
+    else:
+        init["alpha_vb"] = init["sig2_alpha_vb"] = None
     return init
 
 
-def add_intercept_(n, d, list_hyper, list_init, link):
-    """R/locus.R:381-399 (Z = NULL): intercept column with a vague prior for logit/probit."""
-    Z = np.ones((n, 1), order="F")
-    list_hyper["phi"] = np.array([1e-3])
-    list_hyper["xi"] = np.array([1e-3])
-    list_init["alpha_vb"] = np.zeros((1, d))
-    list_init["sig2_alpha_vb"] = np.array([1.0]) if link == "probit" else np.ones((1, d))
-    return Z
+def add_intercept_(n, d, list_hyper, list_init, link, Z=None):
+    """R/locus.R:379-424: intercept column with a vague prior for logit/probit, in front of the
+    user's covariates if any."""
+    one = np.ones((n, 1))
+    if Z is None:
+        list_hyper["phi"] = np.array([1e-3])
+        list_hyper["xi"] = np.array([1e-3])
+        list_init["alpha_vb"] = np.zeros((1, d))
+        list_init["sig2_alpha_vb"] = np.array([1.0]) if link == "probit" else np.ones((1, d))
+        return np.asfortranarray(one)
+    list_hyper["phi"] = np.concatenate([[1e-3], np.atleast_1d(list_hyper["phi"])])
+    list_hyper["xi"] = np.concatenate([[1e-3], np.atleast_1d(list_hyper["xi"])])
+    list_init["alpha_vb"] = np.vstack([np.zeros((1, d)), list_init["alpha_vb"]])
+    if link == "probit":
+        list_init["sig2_alpha_vb"] = np.concatenate([[1.0], np.atleast_1d(list_init["sig2_alpha_vb"])])
+    else:
+        list_init["sig2_alpha_vb"] = np.vstack([np.ones((1, d)), list_init["sig2_alpha_vb"]])
+    return np.asfortranarray(np.hstack([one, Z]))

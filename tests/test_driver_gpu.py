@@ -238,3 +238,16 @@ def test_binary_to_convergence(oracle, hip, link):
     np.testing.assert_allclose(lb_g, lb_r, rtol=1e-8)
     np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], rtol=1e-9, atol=1e-12)
     assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+
+
+def test_locus_entry_point_on_gpu(hip):
+    """locus(Y, X, p0_av) (R/locus.R:240) end to end on the GPU: defaults, convergence at the
+    reference's tol = 0.1, the simulated active SNPs are selected."""
+    from locus_amd import locus
+    from locus_amd.simulate import simulate
+    sim = simulate(200, 500, 20, 15, seed=123)
+    vb = locus(sim["Y"], sim["X"], p0_av=15, user_seed=123, verbose=False)
+    assert vb["converged"] and vb["it"] < 200
+    found = (vb["gam_vb"] > 0.5).any(axis=1)
+    assert found[sim["ind_p0"]].mean() >= 0.8 and found.sum() <= 2 * len(sim["ind_p0"])
+    assert len(vb["rmvd_x"]) == 0 and vb["om_vb"].shape == (500,)
