@@ -121,3 +121,45 @@ def test_mfma_planned_multi_launch(oracle, hip, variant, monkeypatch):
     ref = call_variant(oracle, variant, inp)
     got = call_variant(hip, variant, inp)
     assert_parity(got, ref, what=f"{variant} planned multi-launch")
+
+
+@pytest.mark.parametrize("vector", [False, True])
+def test_partial_sweeps_compose(hip, vector, monkeypatch):
+    """nsteps < p (locus_hip_sweep_args.nsteps): visiting the first k covariates of the order and
+    then the remaining p - k equals one full sweep, on the resident state (both kernels)."""
+    import torch
+    from locus_amd import device as dv
+    monkeypatch.delenv("LOCUS_HIP_SWEEP_CFG", raising=False)
+    if vector:
+        monkeypatch.setenv("LOCUS_HIP_SWEEP_VECTOR", "1")
+    n, p, d, k = 150, 77, 21, 30
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(12)
+    X = rng.normal(size=(n, p))
+    X = np.asfortranarray((X - X.mean(axis=0)) / X.std(axis=0, ddof=1))
+    px = dv.PackedX(dv.to_device_colmajor(X, dev))
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+    gam, mu = rng.random((p, d)) ** 4, rng.normal(scale=0.3, size=(p, d))
+    R0 = rng.normal(size=(d, n))
+    lo, l1 = up(np.full(p, -3.0) + rng.normal(scale=0.1, size=p)), up(np.full(p, -0.05))
+    tau = rng.gamma(2.0, 1.0, size=d)
+    s2 = 1.0 / ((n - 1 + 0.7) * tau)
+    cons = [up(s2 * tau), up(1 / (2 * s2)), up(-(np.log(tau) + np.log(0.7) + np.log(s2)) / 2), up(s2)]
+    perm = rng.permutation(p).astype(np.float64)
+
+    def run(parts):
+        state = torch.empty((3, p, d), dtype=torch.float64, device=dev)
+        state[0], state[1] = up(gam), up(mu)
+        state[2] = state[0] * state[1]
+        R = up(R0).t()
+        sw = dv.Sweeper(px, d, dev)
+        for order, nsteps in parts:
+            sw.identity(up(order), lo, l1, *cons, 1.0, R, state, None, nsteps)
+            sw.status()
+        return state.cpu().numpy(), R.cpu().numpy()
+
+    full_s, full_r = run([(perm, 0)])
+    part_s, part_r = run([(perm, k), (np.roll(perm, -k), p - k)])
+    np.testing.assert_allclose(part_s, full_s, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(part_r, full_r, rtol=1e-10, atol=1e-12)
+    assert not np.array_equal(full_s[0], gam)
