@@ -4,7 +4,7 @@ default hyper-parameters and initial values when none are given, dispatches on l
 list_struct to the device-resident drivers and returns the reference's `vb` fields.
 
 Not rebuilt (out of scope): cross-validation (list_cv), the block fan-out
-(list_blocks), group selection (list_groups) and the mixed identity / probit model (ind_bin);
+(list_blocks) and group selection (list_groups);
 asking for them raises NotImplementedError rather than silently doing something else.
 """
 import numpy as np
@@ -20,11 +20,16 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
     """Arguments and return fields as R/locus.R:240-245, :605-640 (`comm`: response sharding over
     the GPUs of a node, see locus_amd.comm; every rank passes the full arrays)."""
     for name, v in (("list_cv", list_cv), ("list_blocks", list_blocks),
-                    ("list_groups", list_groups), ("ind_bin", ind_bin)):
+                    ("list_groups", list_groups)):
         if v is not None:
             raise NotImplementedError(f"{name} is outside the rebuilt path (SURVEY.md §8)")
-    if link not in ("identity", "logit", "probit"):
-        raise NotImplementedError(f"link = {link!r} is outside the rebuilt path")
+    if link not in ("identity", "logit", "probit", "mix"):
+        raise ValueError("link must be 'identity', 'logit', 'probit' or 'mix'")
+    if (link == "mix") != (ind_bin is not None):             # R/prepare_locus.R:769-785
+        raise ValueError("ind_bin (0-based indices of the binary responses) must be given for "
+                         "link = 'mix' and only then")
+    if ind_bin is not None:
+        ind_bin = np.unique(np.asarray(ind_bin, dtype=np.int64))
     # check_annealing_ (R/utils.R:47-68): annealing only for the identity link without structure
     if anneal is not None and (link != "identity" or list_struct is not None):
         raise ValueError("Annealing has been implemented only for the identity link, "
@@ -34,7 +39,7 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
 
     if verbose:
         print("== Preparing the data ... ")
-    Y, X, bool_rmvd_x = prepare_data_(Y, X, link)
+    Y, X, bool_rmvd_x = prepare_data_(Y, X, link, ind_bin)
     n, d = Y.shape
     p = X.shape[1]
     q = bool_rmvd_z = None
@@ -55,11 +60,13 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
         if np.ndim(p_star) > 0:
             p_star = p_star[~bool_rmvd_x]
     if list_hyper is None:
-        list_hyper = auto_set_hyper_(Y, p, p_star, q=q, link=link, struct=list_struct is not None)
+        list_hyper = auto_set_hyper_(Y, p, p_star, q=q, link=link, struct=list_struct is not None,
+                                     ind_bin=ind_bin)
     else:
         list_hyper = dict(list_hyper)
     if list_init is None:
-        list_init = auto_set_init_(Y, p, p_star, q=q, user_seed=user_seed, link=link)
+        list_init = auto_set_init_(Y, p, p_star, q=q, user_seed=user_seed, link=link,
+                                   ind_bin=ind_bin)
     else:
         list_init = dict(list_init)
     if link != "identity":
@@ -81,6 +88,11 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
         vb = locus_z_core_(Y, X, Z, list_hyper, li["gam_vb"], li["alpha_vb"], li["mu_beta_vb"],
                            li["sig2_alpha_vb"], li["sig2_beta_vb"], li["tau_vb"], anneal=anneal,
                            **kw)
+    elif link == "mix":
+        from .locus_mix_core import locus_mix_core_
+        vb = locus_mix_core_(Y, X, Z, ind_bin, list_hyper, li["gam_vb"], li["alpha_vb"],
+                             li["mu_beta_vb"], li["sig2_alpha_vb"], li["sig2_beta_vb"],
+                             li["tau_vb"], **kw)
     else:
         from . import locus_bin_core
         fn = getattr(locus_bin_core, f"locus_{link}_core_")

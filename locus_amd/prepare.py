@@ -25,7 +25,7 @@ def scale_rm_(X):
     return Xs, bool_rmvd
 
 
-def prepare_data_(Y, X, link="identity"):
+def prepare_data_(Y, X, link="identity", ind_bin=None):
     """R/prepare_locus.R:109-141: scale(X) (centre, sd with n-1), drop constant and duplicated
     columns, centre Y (identity) / subtract 1/2 (logit).  Returns (Y, X, bool_rmvd_x)."""
     Y = np.asarray(Y, dtype=np.float64)
@@ -34,6 +34,10 @@ def prepare_data_(Y, X, link="identity"):
         raise ValueError("There must be at least 1 non-constant candidate predictor stored in X.")
     if link == "identity":
         Y = Y - Y.mean(axis=0)
+    elif link == "mix":                                      # R/prepare_locus.R:133-135
+        cont = np.setdiff1d(np.arange(Y.shape[1]), ind_bin)
+        Y = Y.copy()
+        Y[:, cont] = Y[:, cont] - Y[:, cont].mean(axis=0)
     elif link == "logit":
         Y = Y - 0.5
     return np.asfortranarray(Y), np.asfortranarray(Xs), bool_rmvd_x
@@ -57,18 +61,21 @@ def convert_p0_av_(p0_av, p):
     return p0_av * p
 
 
-def auto_set_hyper_(Y, p, p_star, q=None, link="identity", struct=False):
-    """R/set_hyper_init.R:321-419 (no groups, no mix)."""
+def auto_set_hyper_(Y, p, p_star, q=None, link="identity", struct=False, ind_bin=None):
+    """R/set_hyper_init.R:321-419 (no groups).  link = "mix": eta, kappa for the continuous
+    responses only (:342-344), ind_bin 0-based."""
     d = Y.shape[1]
+    if link == "mix":
+        Y = Y[:, np.setdiff1d(np.arange(d), ind_bin)]
     h = dict(d_hyper=d, p_hyper=p, q_hyper=q, link_hyper=link)
     h["lambda"] = 1e-2
     h["nu"] = 1.0
-    if link == "identity":
+    if link in ("identity", "mix"):
         eta = 1.0 / np.median(Y.var(axis=0, ddof=1))
         if not np.isfinite(eta):
             eta = 1e3
-        h["eta"] = np.full(d, eta)
-        h["kappa"] = np.ones(d)
+        h["eta"] = np.full(Y.shape[1], eta)
+        h["kappa"] = np.ones(Y.shape[1])
     else:
         h["eta"] = h["kappa"] = None
     a = np.ones(p)
@@ -90,8 +97,9 @@ def auto_set_hyper_(Y, p, p_star, q=None, link="identity", struct=False):
     return h
 
 
-def auto_set_init_(Y, p, p_star, q=None, user_seed=None, link="identity"):
-    """R/set_hyper_init.R:750-874 (no groups, no mix)."""
+def auto_set_init_(Y, p, p_star, q=None, user_seed=None, link="identity", ind_bin=None):
+    """R/set_hyper_init.R:750-874 (no groups); link = "mix": tau_vb = 1 at the binary responses
+    (:783-799), ind_bin 0-based."""
     d = Y.shape[1]
     rng = np.random.default_rng(user_seed)
     shape2 = d * (p - np.asarray(p_star, dtype=np.float64)) / p_star
@@ -103,11 +111,13 @@ def auto_set_init_(Y, p, p_star, q=None, user_seed=None, link="identity"):
     sig2_inv_vb = 1e-2
     init = dict(d_init=d, p_init=p, q_init=q, link_init=link, gam_vb=np.asfortranarray(gam_vb),
                 mu_beta_vb=np.asfortranarray(mu_beta_vb), sig2_inv_vb=sig2_inv_vb)
-    if link == "identity":
-        tau = 1.0 / np.median(Y.var(axis=0, ddof=1))
+    if link in ("identity", "mix"):
+        cont = np.arange(d) if link == "identity" else np.setdiff1d(np.arange(d), ind_bin)
+        tau = 1.0 / np.median(Y[:, cont].var(axis=0, ddof=1))
         if not np.isfinite(tau):
             tau = 1e3
-        tau_vb = np.full(d, tau)
+        tau_vb = np.ones(d)
+        tau_vb[cont] = tau
         init["tau_vb"] = tau_vb
         # 1 / rgamma(d, shape = 2, rate = 1 / (sig2_inv_vb * tau_vb))
         init["sig2_beta_vb"] = 1.0 / rng.gamma(2.0, sig2_inv_vb * tau_vb, size=d)
@@ -119,7 +129,7 @@ def auto_set_init_(Y, p, p_star, q=None, user_seed=None, link="identity"):
         init["sig2_beta_vb"] = float(1.0 / rng.gamma(2.0, sig2_inv_vb))
     if q is not None:                                        # R/set_hyper_init.R:823-848
         init["alpha_vb"] = rng.normal(size=(q, d))
-        if link == "identity":
+        if link in ("identity", "mix"):
             zeta2_inv_vb = rng.gamma(1.0, 1.0, size=q)
             init["sig2_alpha_vb"] = 1.0 / rng.gamma(2.0, np.outer(zeta2_inv_vb, init["tau_vb"]))
         elif link == "logit":

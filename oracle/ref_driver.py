@@ -941,6 +941,148 @@ def locus_z_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_
 
 
 # --------------------------------------------------------------------------- #
+# R/locus_mix_core.R (identity link for some responses, probit for the others)
+# --------------------------------------------------------------------------- #
+def elbo_mix_(Y_bin, Y_cont, ind_bin, X, Z, a, a_vb, b, b_vb, beta_vb, eta, gam_vb, kappa, lam,
+              alpha_vb, nu, phi, phi_vb, sig2_alpha_vb, sig2_beta_vb, sig2_inv_vb, tau_vb,
+              log_tau_vb, xi, zeta2_inv_vb, m2_alpha, m2_beta, mat_x_m1, mat_z_mu, sum_gam):
+    """R/locus_mix_core.R:287-349; ind_bin 0-based, `cont` its complement."""
+    n, q = Z.shape
+    d = gam_vb.shape[1]
+    cont = np.setdiff1d(np.arange(d), ind_bin)
+    xi_vb = update_xi_z_vb_(xi, tau_vb, m2_alpha)
+    eta_vb = update_eta_z_vb_(n, q, eta, gam_vb[:, cont])
+    kappa_vb = (update_kappa_z_vb_(Y_cont, kappa, alpha_vb[:, cont], beta_vb[:, cont],
+                                   m2_alpha[:, cont], m2_beta[:, cont], mat_x_m1[:, cont],
+                                   mat_z_mu[:, cont], sig2_inv_vb, zeta2_inv_vb)
+                + (m2_alpha[0, cont] - alpha_vb[0, cont] ** 2) / 2)     # intercept = TRUE
+    lambda_vb = update_lambda_vb_(lam, sum_gam)
+    nu_vb = update_nu_vb_(nu, m2_beta, tau_vb)
+    log_tau_vb = log_tau_vb.copy()
+    log_tau_vb[cont] = digamma(eta_vb) - np.log(kappa_vb)
+    log_zeta2_inv_vb = digamma(phi_vb) - np.log(xi_vb)
+    log_sig2_inv_vb = digamma(lambda_vb) - np.log(nu_vb)
+    log_om_vb = digamma(a_vb) - digamma(a_vb + b_vb)
+    log_1_min_om_vb = digamma(b_vb) - digamma(a_vb + b_vb)
+    elbo_A_cont = (e_y_(n, kappa, kappa_vb, log_tau_vb[cont], m2_beta[:, cont], sig2_inv_vb,
+                        tau_vb[cont])
+                   + np.sum(tau_vb[cont] * (m2_alpha[:, cont].T @ zeta2_inv_vb) / 2))
+    U = mat_x_m1[:, ind_bin] + mat_z_mu[:, ind_bin]                     # e_y_probit_, sweep = FALSE
+    elbo_A_bin = np.sum(Y_bin * log_ndtr(U) + (1 - Y_bin) * log_ndtr(-U)
+                        - (X ** 2) @ (m2_beta[:, ind_bin] - beta_vb[:, ind_bin] ** 2) / 2
+                        - (Z ** 2) @ sig2_alpha_vb[:, ind_bin] / 2)
+    elbo_B = e_beta_gamma_(gam_vb, log_om_vb, log_1_min_om_vb, log_sig2_inv_vb, log_tau_vb,
+                           m2_beta, sig2_beta_vb, sig2_inv_vb, tau_vb)
+    elbo_C = e_tau_(eta, eta_vb, kappa, kappa_vb, log_tau_vb[cont], tau_vb[cont])
+    elbo_D = e_sig2_inv_(lam, lambda_vb, log_sig2_inv_vb, nu, nu_vb, sig2_inv_vb)
+    elbo_E = e_omega_(a, a_vb, b, b_vb, log_om_vb, log_1_min_om_vb)
+    elbo_F = e_alpha_(m2_alpha, log_tau_vb, log_zeta2_inv_vb, sig2_alpha_vb, tau_vb,
+                      zeta2_inv_vb)
+    elbo_G = e_zeta2_inv_(log_zeta2_inv_vb, phi, phi_vb, xi, xi_vb, zeta2_inv_vb)
+    return elbo_A_cont + elbo_A_bin + elbo_B + elbo_C + elbo_D + elbo_E + elbo_F + elbo_G
+
+
+def locus_mix_core_(Y, X, Z, ind_bin, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
+                    sig2_beta_vb, tau_vb, tol, maxit, perm_fn, alpha_perm_fn=None, debug=False,
+                    trace=None):
+    """R/locus_mix_core.R:8-280, scheme batch = "y".  ind_bin: 0-based indices of the binary (0/1)
+    responses; the continuous ones are centred; Z[:, 0] is the intercept; eta, kappa have one
+    entry per continuous response; tau_vb has length d with 1 at the binary responses."""
+    Y = np.asfortranarray(Y, dtype=np.float64)
+    X = np.asfortranarray(X, dtype=np.float64)
+    Z = np.asfortranarray(Z, dtype=np.float64)
+    n, d = Y.shape
+    p, q = X.shape[1], Z.shape[1]
+    ind_bin = np.asarray(ind_bin, dtype=np.int64)
+    cont = np.setdiff1d(np.arange(d), ind_bin)
+    a, b = list_hyper["a"], list_hyper["b"]
+    eta, kappa = list_hyper["eta"], list_hyper["kappa"]
+    lam, nu = list_hyper["lambda"], list_hyper["nu"]
+    phi = np.atleast_1d(np.asarray(list_hyper["phi"], dtype=np.float64))
+    xi = np.atleast_1d(np.asarray(list_hyper["xi"], dtype=np.float64))
+    gam_vb = np.asfortranarray(gam_vb, dtype=np.float64).copy(order="F")
+    mu_beta_vb = np.asfortranarray(mu_beta_vb, dtype=np.float64).copy(order="F")
+    alpha_vb = np.array(alpha_vb, dtype=np.float64).reshape(q, d)
+    sig2_alpha_vb = np.array(sig2_alpha_vb, dtype=np.float64).reshape(q, d)
+    sig2_beta_vb = np.array(sig2_beta_vb, dtype=np.float64)
+    tau_vb = np.array(tau_vb, dtype=np.float64)
+
+    W = Y.copy(order="F")
+    Y_bin, Y_cont = Y[:, ind_bin], Y[:, cont]
+    m2_alpha = update_m2_alpha_(alpha_vb, sig2_alpha_vb)                # :27
+    beta_vb = update_beta_vb_(gam_vb, mu_beta_vb)
+    m2_beta = update_m2_beta_(gam_vb, mu_beta_vb, sig2_beta_vb, sweep=True)
+    mat_x_m1 = np.asfortranarray(X @ beta_vb)
+    mat_z_mu = np.asfortranarray(Z @ alpha_vb)
+    W[:, ind_bin] = update_W_probit_(Y_bin, mat_z_mu[:, ind_bin], mat_x_m1[:, ind_bin])
+    phi_vb = update_phi_z_vb_(phi, d)
+    rs_gam = gam_vb.sum(axis=1)
+    sum_gam = rs_gam.sum()
+    digam_sum = digamma(a + b + d)
+    log_tau_vb = np.zeros(d)
+    converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
+    om_vb = None
+    den_add = np.zeros(q)
+    den_add[0] = 1.0                                                    # intercept = TRUE
+
+    while (not converged) and it < maxit:
+        lb_old = lb_new
+        it += 1
+        xi_vb = update_xi_z_vb_(xi, tau_vb, m2_alpha)                   # :62-64
+        zeta2_inv_vb = phi_vb / xi_vb
+        lambda_vb = update_lambda_vb_(lam, sum_gam)
+        nu_vb = update_nu_vb_(nu, m2_beta, tau_vb)
+        sig2_inv_vb = lambda_vb / nu_vb
+        eta_vb = update_eta_z_vb_(n, q, eta, gam_vb[:, cont])           # :74-87
+        kappa_vb = (update_kappa_z_vb_(Y_cont, kappa, alpha_vb[:, cont], beta_vb[:, cont],
+                                       m2_alpha[:, cont], m2_beta[:, cont], mat_x_m1[:, cont],
+                                       mat_z_mu[:, cont], sig2_inv_vb, zeta2_inv_vb)
+                    + (m2_alpha[0, cont] - alpha_vb[0, cont] ** 2) / 2)
+        tau_vb[cont] = eta_vb / kappa_vb
+        sig2_alpha_vb = 1 / np.outer(n - 1 + zeta2_inv_vb + den_add, tau_vb)   # :90
+        sig2_beta_vb = update_sig2_beta_vb_(n, sig2_inv_vb, tau_vb)
+        log_tau_vb[cont] = update_log_tau_vb_(eta_vb, kappa_vb)
+        log_sig2_inv_vb = update_log_sig2_inv_vb_(lambda_vb, nu_vb)
+        log_om_vb = update_log_om_vb(a, digam_sum, rs_gam)              # :101-102
+        log_1_min_om_vb = update_log_1_min_om_vb(b, d, digam_sum, rs_gam)
+
+        order = range(q) if alpha_perm_fn is None else alpha_perm_fn(it)
+        for i in order:                                                 # :104-111
+            mat_z_mu = mat_z_mu - np.outer(Z[:, i], alpha_vb[i, :])
+            alpha_vb[i, :] = sig2_alpha_vb[i, :] * (tau_vb * ((W - mat_z_mu - mat_x_m1).T @ Z[:, i]))
+            mat_z_mu = mat_z_mu + np.outer(Z[:, i], alpha_vb[i, :])
+        mat_z_mu = np.asfortranarray(mat_z_mu)
+
+        shuffled_ind = np.ascontiguousarray(perm_fn(it), dtype=np.float64)
+        c_oracle.coreZLoop(X, W, gam_vb, log_om_vb, log_1_min_om_vb, log_sig2_inv_vb,
+                           log_tau_vb, beta_vb, mat_x_m1, mat_z_mu, mu_beta_vb, sig2_beta_vb,
+                           tau_vb, shuffled_ind)                        # :116-118
+        rs_gam = gam_vb.sum(axis=1)
+
+        m2_alpha = update_m2_alpha_(alpha_vb, sig2_alpha_vb)            # :215-221
+        m2_beta = update_m2_beta_(gam_vb, mu_beta_vb, sig2_beta_vb, sweep=True)
+        W[:, ind_bin] = update_W_probit_(Y_bin, mat_z_mu[:, ind_bin], mat_x_m1[:, ind_bin])
+        a_vb = update_a_vb(a, rs_gam)
+        b_vb = update_b_vb(b, d, rs_gam)
+        om_vb = a_vb / (a_vb + b_vb)
+        sum_gam = rs_gam.sum()
+        lb_new = elbo_mix_(Y_bin, Y_cont, ind_bin, X, Z, a, a_vb, b, b_vb, beta_vb, eta, gam_vb,
+                           kappa, lam, alpha_vb, nu, phi, phi_vb, sig2_alpha_vb, sig2_beta_vb,
+                           sig2_inv_vb, tau_vb, log_tau_vb, xi, zeta2_inv_vb, m2_alpha, m2_beta,
+                           mat_x_m1, mat_z_mu, sum_gam)
+        if trace is not None:
+            trace.append((it, float(lb_new)))
+        if debug and lb_new < lb_old:
+            raise RuntimeError("ELBO not increasing monotonically. Exit. ")
+        converged = abs(lb_new - lb_old) < tol
+
+    return dict(beta_vb=beta_vb, gam_vb=gam_vb, om_vb=om_vb, alpha_vb=alpha_vb,
+                converged=converged, it=it, lb_opt=lb_new, diff_lb=abs(lb_new - lb_old),
+                mu_beta_vb=mu_beta_vb, mat_x_m1=mat_x_m1, mat_z_mu=mat_z_mu,
+                sig2_alpha_vb=sig2_alpha_vb, sig2_beta_vb=sig2_beta_vb, tau_vb=tau_vb)
+
+
+# --------------------------------------------------------------------------- #
 # Second, independent restatement of one sweep -- used only to cross-check the C
 # oracle.  It is taken from the scalar R formulas of the "batch 0" scheme
 # (R/locus_core.R:144-155), i.e. a different operand association from the C++

@@ -88,6 +88,30 @@ def test_z_covariates_driver(oracle, hip, anneal):
     assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
 
 
+def test_mix_driver(oracle, hip):
+    """locus_mix_core_ (R/locus_mix_core.R): continuous and binary responses interleaved,
+    intercept + 2 covariates, against the numpy restatement; 4 iterations."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_drivers_cpu import _mix_problem
+    from oracle import ref_driver
+    from locus_amd.locus_mix_core import locus_mix_core_
+    sim, hyper, init, extra, perm_fn, aperm_fn = _mix_problem(n=150, p=300, d=37, p0=10, seed=5)
+    args = (sim["Y"], sim["X"], extra["Z"], extra["ind_bin"], hyper, init["gam_vb"],
+            init["alpha_vb"], init["mu_beta_vb"], init["sig2_alpha_vb"], init["sig2_beta_vb"],
+            init["tau_vb"])
+    kw = dict(tol=1e-30, maxit=4, perm_fn=perm_fn, alpha_perm_fn=aperm_fn)
+    ref = ref_driver.locus_mix_core_(*args, **kw)
+    got = locus_mix_core_(*args, full_output=True, **kw)
+    assert got["it"] == ref["it"] == 4
+    for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1", "alpha_vb", "mat_z_mu",
+              "sig2_alpha_vb", "tau_vb"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-11, err_msg=k)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+    assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+
+
 def test_identity_to_convergence_recovers_actives(oracle, hip):
     from oracle import ref_driver
     from locus_amd.locus_core import locus_core_

@@ -24,7 +24,7 @@ for pth in (ROOT, HERE):
 
 N, P, D, P0 = 60, 80, 7, 6
 MAXIT = 3
-KINDS = ["identity", "anneal", "struct", "logit", "probit", "z", "z-anneal"]
+KINDS = ["identity", "anneal", "struct", "logit", "probit", "z", "z-anneal", "mix"]
 
 
 def _problem(kind):
@@ -48,6 +48,8 @@ def _problem(kind):
         init["alpha_vb"] = rng.normal(scale=0.1, size=(2, D))
         init["sig2_alpha_vb"] = (np.array([1.0, 0.5]) if link == "probit"
                                  else rng.gamma(2.0, 0.2, size=(2, D)))
+    if kind == "mix":
+        return _mix_problem()
     if kind in ("z", "z-anneal"):
         rng = np.random.default_rng(4)
         Zc = rng.normal(size=(N, 3))
@@ -66,12 +68,52 @@ def _problem(kind):
     return sim, hyper, init, extra, (lambda it: perms[it]), (lambda it: aperms[it])
 
 
+def _mix_problem(n=N, p=P, d=D, p0=P0, seed=17):
+    """Continuous (centred) and binary (0/1) responses interleaved; Z = intercept + 2 covariates."""
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_
+    from locus_amd.simulate import simulate
+    sim = simulate(n, p, d, p0, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    ind_bin = np.sort(rng.choice(d, size=max(1, d // 2 - 1), replace=False))
+    cont = np.setdiff1d(np.arange(d), ind_bin)
+    Y = sim["Y"].copy()
+    Y[:, ind_bin] = (Y[:, ind_bin] > 0).astype(np.float64)
+    sim = dict(sim, Y=np.asfortranarray(Y))
+    hyper = auto_set_hyper_(Y[:, cont], p, p0)
+    b_full = d * (p - p0) / p0
+    hyper["b"] = np.full(p, b_full)
+    hyper["phi"], hyper["xi"] = np.array([1e-3, 1.0, 1.0]), np.array([1e-3, 1.0, 0.5])
+    init = auto_set_init_(Y, p, p0, user_seed=seed)
+    tau = np.ones(d)
+    tau[cont] = 1.0 / np.median(Y[:, cont].var(axis=0, ddof=1))
+    init["tau_vb"] = tau
+    init["sig2_beta_vb"] = 1.0 / rng.gamma(2.0, 1e-2 * tau)
+    Zc = rng.normal(size=(n, 2))
+    Zc = (Zc - Zc.mean(axis=0)) / Zc.std(axis=0, ddof=1)
+    extra = dict(Z=np.asfortranarray(np.hstack([np.ones((n, 1)), Zc])), ind_bin=ind_bin)
+    init["alpha_vb"] = rng.normal(scale=0.1, size=(3, d))
+    init["sig2_alpha_vb"] = rng.gamma(2.0, 0.3, size=(3, d))
+    perms = [np.random.default_rng(50 + i).permutation(p).astype(np.float64) for i in range(16)]
+    aperms = [np.random.default_rng(90 + i).permutation(3) for i in range(16)]
+    return sim, hyper, init, extra, (lambda it: perms[it]), (lambda it: aperms[it])
+
+
 def _run(kind, which, comm=None):
     """which = 'ref' (oracle/ref_driver.py, full matrices) or 'got' (product host side on the
     CPU emulation of the device layer)."""
     sim, hyper, init, extra, perm_fn, aperm_fn = _problem(kind)
     Y, X = sim["Y"], sim["X"]
     common = dict(tol=1e-30, maxit=MAXIT, perm_fn=perm_fn)
+    if kind == "mix":
+        args = (Y, X, extra["Z"], extra["ind_bin"], hyper, init["gam_vb"], init["alpha_vb"],
+                init["mu_beta_vb"], init["sig2_alpha_vb"], init["sig2_beta_vb"], init["tau_vb"])
+        if which == "ref":
+            from oracle import ref_driver as R
+            return R.locus_mix_core_(*args, alpha_perm_fn=aperm_fn, **common)
+        import cpu_device
+        from locus_amd.locus_mix_core import locus_mix_core_
+        return locus_mix_core_(*args, alpha_perm_fn=aperm_fn, comm=comm, full_output=True,
+                               _test_backend=cpu_device, **common)
     if kind in ("z", "z-anneal"):
         an = (1, 2.0, 2) if kind == "z-anneal" else None
         args = (Y, X, extra["Z"], hyper, init["gam_vb"], init["alpha_vb"], init["mu_beta_vb"],
@@ -115,7 +157,7 @@ def _run(kind, which, comm=None):
 def _compare(kind, got, ref):
     assert got["it"] == ref["it"] == MAXIT
     keys = ["gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1"]
-    if kind in ("logit", "probit", "z", "z-anneal"):
+    if kind in ("logit", "probit", "z", "z-anneal", "mix"):
         keys += ["alpha_vb", "mat_z_mu"]
     for k in keys:
         np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=f"{kind} {k}")

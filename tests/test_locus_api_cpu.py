@@ -23,7 +23,7 @@ def _data(link="identity"):
     return sim, X
 
 
-@pytest.mark.parametrize("mode", ["identity", "z", "struct", "logit", "probit"])
+@pytest.mark.parametrize("mode", ["identity", "z", "struct", "logit", "probit", "mix"])
 def test_locus_dispatch_and_preparation(oracle, mode):
     import cpu_device
     from locus_amd.locus import locus
@@ -34,6 +34,11 @@ def test_locus_dispatch_and_preparation(oracle, mode):
               _test_backend=cpu_device)
     if mode == "z":
         kw["Z"] = np.random.default_rng(1).normal(size=(N, 2))
+    if mode == "mix":
+        Yb = sim["Y"].copy()
+        Yb[:, [1, 4]] = (Yb[:, [1, 4]] > 0).astype(np.float64)
+        sim = dict(sim, Y=Yb)
+        kw.update(link="mix", ind_bin=[1, 4])
     if mode == "struct":
         kw["list_struct"] = set_struct(N, X.shape[1], np.arange(1, X.shape[1] + 1, 20))
     vb = locus(sim["Y"], X, P0, **kw)
@@ -42,7 +47,7 @@ def test_locus_dispatch_and_preparation(oracle, mode):
     assert np.isfinite(vb["lb_opt"]) and np.all((vb["gam_vb"] >= 0) & (vb["gam_vb"] <= 1))
     if mode == "z":
         assert vb["alpha_vb"].shape == (2, D)
-    if link != "identity":
+    if link != "identity" or mode == "mix":
         assert vb["alpha_vb"].shape == (1, D)                 # the added intercept
 
 
@@ -50,9 +55,11 @@ def test_locus_refuses_what_is_out_of_scope(oracle):
     import cpu_device
     from locus_amd.locus import locus
     sim, X = _data()
-    for kw in (dict(list_cv={}), dict(list_blocks={}), dict(list_groups={}), dict(ind_bin=[1])):
+    for kw in (dict(list_cv={}), dict(list_blocks={}), dict(list_groups={})):
         with pytest.raises(NotImplementedError):
             locus(sim["Y"], X, P0, _test_backend=cpu_device, verbose=False, **kw)
+    with pytest.raises(ValueError):
+        locus(sim["Y"], X, P0, ind_bin=[1], _test_backend=cpu_device, verbose=False)
     with pytest.raises(ValueError):
         locus(sim["Y"], X, P0, link="logit", anneal=(1, 2.0, 3), _test_backend=cpu_device,
               verbose=False)
