@@ -3,8 +3,8 @@ paths rebuilt here.  Prepares the data (standardisation, constant / duplicated c
 default hyper-parameters and initial values when none are given, dispatches on link / Z /
 list_struct to the device-resident drivers and returns the reference's `vb` fields.
 
-Not rebuilt (out of scope): cross-validation (list_cv), the block fan-out
-(list_blocks) and group selection (list_groups);
+Not rebuilt (out of scope): cross-validation (list_cv) and group selection
+(list_groups);
 asking for them raises NotImplementedError rather than silently doing something else.
 """
 import numpy as np
@@ -19,8 +19,7 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
           checkpoint_path=None, comm=None, device=None, _test_backend=None):
     """Arguments and return fields as R/locus.R:240-245, :605-640 (`comm`: response sharding over
     the GPUs of a node, see locus_amd.comm; every rank passes the full arrays)."""
-    for name, v in (("list_cv", list_cv), ("list_blocks", list_blocks),
-                    ("list_groups", list_groups)):
+    for name, v in (("list_cv", list_cv), ("list_groups", list_groups)):
         if v is not None:
             raise NotImplementedError(f"{name} is outside the rebuilt path (SURVEY.md §8)")
     if link not in ("identity", "logit", "probit", "mix"):
@@ -34,6 +33,8 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
     if anneal is not None and (link != "identity" or list_struct is not None):
         raise ValueError("Annealing has been implemented only for the identity link, "
                          "without structured sparsity")
+    if list_blocks is not None and list_struct is not None:      # prepare_blocks_ (:611-613)
+        raise ValueError("list_blocks and list_struct can't be both non-NULL.")
     if list_struct is not None and (link != "identity" or Z is not None):
         raise ValueError("list_struct requires link = 'identity' and Z = NULL")  # set_hyper:211
 
@@ -54,9 +55,16 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
         list_struct = dict(list_struct)
         list_struct["vec_fac_st"] = np.asarray(list_struct["vec_fac_st"])[~bool_rmvd_x]
 
+    vec_fac_bl = n_bl = None
+    if list_blocks is not None:                                  # prepare_blocks_ (:594-631)
+        if list_blocks["p_blocks"] != len(bool_rmvd_x):
+            raise ValueError("The number of candidate predictors given to set_blocks is not "
+                             "consistent with X.")
+        vec_fac_bl = np.asarray(list_blocks["vec_fac_bl"])[~bool_rmvd_x]
+        n_bl = len(np.unique(vec_fac_bl))
     p_star = None
     if list_hyper is None or list_init is None:
-        p_star = convert_p0_av_(p0_av, len(bool_rmvd_x))
+        p_star = convert_p0_av_(p0_av, len(bool_rmvd_x), n_bl)
         if np.ndim(p_star) > 0:
             p_star = p_star[~bool_rmvd_x]
     if list_hyper is None:
@@ -72,8 +80,23 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
     if link != "identity":
         Z = add_intercept_(n, d, list_hyper, list_init, link, Z)
 
-    kw = dict(tol=tol, maxit=maxit, verbose=verbose, full_output=full_output, comm=comm,
-              device=device, _test_backend=_test_backend)
+    if vec_fac_bl is not None:
+        vb = _run_blocks(Y, X, Z, link, ind_bin, list_hyper, list_init, vec_fac_bl, tol, maxit,
+                         anneal, full_output, comm, device, _test_backend)
+    else:
+        vb = _run_one(Y, X, Z, link, ind_bin, list_hyper, list_init, list_struct, anneal,
+                      checkpoint_path, dict(tol=tol, maxit=maxit, verbose=verbose,
+                                            full_output=full_output, comm=comm, device=device,
+                                            _test_backend=_test_backend))
+    vb["p_star"] = p_star
+    vb["rmvd_x"] = np.nonzero(bool_rmvd_x)[0]                    # R/locus.R:620-626
+    vb["rmvd_z"] = None if bool_rmvd_z is None else np.nonzero(bool_rmvd_z)[0]
+    return vb
+
+
+def _run_one(Y, X, Z, link, ind_bin, list_hyper, list_init, list_struct, anneal, checkpoint_path,
+             kw):
+    """Dispatch of R/locus.R:447-503 on link / Z / list_struct."""
     li = list_init
     if link == "identity" and list_struct is not None:
         from .locus_struct_core import locus_struct_core_
@@ -98,7 +121,43 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
         fn = getattr(locus_bin_core, f"locus_{link}_core_")
         vb = fn(Y, X, Z, list_hyper, li["gam_vb"], li["alpha_vb"], li["mu_beta_vb"],
                 li["sig2_alpha_vb"], li["sig2_beta_vb"], **kw)
-    vb["p_star"] = p_star
-    vb["rmvd_x"] = np.nonzero(bool_rmvd_x)[0]                    # R/locus.R:620-626
-    vb["rmvd_z"] = None if bool_rmvd_z is None else np.nonzero(bool_rmvd_z)[0]
     return vb
+
+
+def _run_blocks(Y, X, Z, link, ind_bin, list_hyper, list_init, vec_fac_bl, tol, maxit, anneal,
+                full_output, comm, device, _test_backend):
+    """Block-wise inference (R/locus.R:505-603): the candidate predictors are split into blocks
+    that are fitted independently, each with all the responses.  The reference fans the blocks out
+    over CPU cores (parallel::mclapply, :590); here they run one after the other on the GPU, or --
+    with a communicator of several ranks -- block k on rank k mod world, each rank fitting its
+    blocks on its own GPU without response sharding, results exchanged at the end."""
+    labels = np.unique(vec_fac_bl)
+    rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+    mine = {}
+    for k, lab in enumerate(labels):
+        if k % world != rank:
+            continue
+        pos = np.nonzero(vec_fac_bl == lab)[0]
+        hy = dict(list_hyper)                                    # :509-514
+        hy["a"], hy["b"] = np.asarray(list_hyper["a"])[pos], np.asarray(list_hyper["b"])[pos]
+        li = dict(list_init)                                     # :516-523
+        li["gam_vb"] = np.asarray(list_init["gam_vb"])[pos]
+        li["mu_beta_vb"] = np.asarray(list_init["mu_beta_vb"])[pos]
+        if link == "logit":
+            li["sig2_beta_vb"] = np.asarray(list_init["sig2_beta_vb"])[pos]
+        kw = dict(tol=tol, maxit=maxit, verbose=False, full_output=full_output, comm=None,
+                  device=device, _test_backend=_test_backend)
+        vb = _run_one(Y, np.asfortranarray(X[:, pos]), Z, link, ind_bin, hy, li, None, anneal, None,
+                      kw)
+        mine[k] = {key: vb[key] for key in ("converged", "it", "lb_opt", "om_vb", "gam_vb")}
+    if world > 1:
+        import torch.distributed as dist
+        parts = [None] * world
+        dist.all_gather_object(parts, mine, group=comm.group)
+        mine = {k: v for part in parts for k, v in part.items()}
+    order = range(len(labels))
+    return dict(converged=np.array([mine[k]["converged"] for k in order]),       # :592-601
+                it=np.array([mine[k]["it"] for k in order]),
+                lb_opt=np.array([mine[k]["lb_opt"] for k in order]),
+                om_vb=np.concatenate([mine[k]["om_vb"] for k in order]),
+                gam_vb=np.asfortranarray(np.vstack([mine[k]["gam_vb"] for k in order])))

@@ -43,8 +43,31 @@ def prepare_data_(Y, X, link="identity", ind_bin=None):
     return np.asfortranarray(Y), np.asfortranarray(Xs), bool_rmvd_x
 
 
-def convert_p0_av_(p0_av, p):
-    """R/prepare_locus.R:155-214 (scalar or length-p p0_av, no blocks)."""
+def set_blocks(p, pos_bl):
+    """R/prepare_locus.R:701-761: partition of the p candidate predictors into consecutive blocks;
+    pos_bl = first index (1-based, as in R) of every block.  (n_cpus has no counterpart: blocks
+    run one after the other on a GPU, or one block per rank, see locus_amd.locus.)"""
+    pos_bl = np.asarray(pos_bl, dtype=np.int64)
+    if (pos_bl < 1).any() or (pos_bl > p).any():
+        raise ValueError("The positions provided in pos_bl must range between 1 and p.")
+    if len(np.unique(pos_bl)) != len(pos_bl) or (np.diff(pos_bl) <= 0).any():
+        raise ValueError("The positions provided in pos_bl must be unique and increasing.")
+    vec_fac_bl = np.cumsum(np.isin(np.arange(1, p + 1), pos_bl))
+    return dict(p_blocks=int(p), n_bl=len(np.unique(vec_fac_bl)), vec_fac_bl=vec_fac_bl)
+
+
+def convert_p0_av_(p0_av, p, n_bl=None):
+    """R/prepare_locus.R:155-214 (scalar or length-p p0_av); n_bl: number of blocks of a
+    block-wise run, for which the sparsity level is adapted (:205-212)."""
+    p_star = _convert_p0_av(p0_av, p)
+    if n_bl is not None:
+        p_star = np.minimum(np.asarray(p_star, dtype=np.float64) * n_bl, 0.975 * p)
+        if p_star.ndim == 0:
+            p_star = float(p_star)
+    return p_star
+
+
+def _convert_p0_av(p0_av, p):
     eps = np.finfo(np.float64).eps ** 0.5
     p0_av = np.atleast_1d(np.asarray(p0_av, dtype=np.float64))
     if p0_av.size == 1:

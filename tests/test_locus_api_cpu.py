@@ -55,7 +55,7 @@ def test_locus_refuses_what_is_out_of_scope(oracle):
     import cpu_device
     from locus_amd.locus import locus
     sim, X = _data()
-    for kw in (dict(list_cv={}), dict(list_blocks={}), dict(list_groups={})):
+    for kw in (dict(list_cv={}), dict(list_groups={})):
         with pytest.raises(NotImplementedError):
             locus(sim["Y"], X, P0, _test_backend=cpu_device, verbose=False, **kw)
     with pytest.raises(ValueError):
@@ -63,3 +63,74 @@ def test_locus_refuses_what_is_out_of_scope(oracle):
     with pytest.raises(ValueError):
         locus(sim["Y"], X, P0, link="logit", anneal=(1, 2.0, 3), _test_backend=cpu_device,
               verbose=False)
+
+
+def _blocks_run(comm=None):
+    import cpu_device
+    from locus_amd.locus import locus
+    from locus_amd.prepare import set_blocks
+    sim, X = _data()
+    lb = set_blocks(X.shape[1], [1, 21, 45])                  # 3 blocks over the raw columns
+    return sim, X, locus(sim["Y"], X, P0, list_blocks=lb, user_seed=3, tol=1e-30, maxit=3,
+                         verbose=False, comm=comm, _test_backend=cpu_device)
+
+
+def test_locus_block_wise_equals_per_block_fits(oracle):
+    """list_blocks (R/locus.R:505-603): every block of predictors is an independent fit with all
+    the responses; p_star is scaled by the number of blocks (R/prepare_locus.R:205-212)."""
+    import cpu_device
+    from locus_amd.locus_core import locus_core_
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_, prepare_data_
+    sim, X, vb = _blocks_run()
+    assert vb["gam_vb"].shape == (P, D) and vb["it"].shape == (3,) and vb["om_vb"].shape == (P,)
+    assert vb["p_star"] == P0 * 3
+    Yc, Xs, rm = prepare_data_(sim["Y"], X)
+    hy = auto_set_hyper_(Yc, P, P0 * 3)
+    ini = auto_set_init_(Yc, P, P0 * 3, user_seed=3)
+    fac = np.cumsum(np.isin(np.arange(1, X.shape[1] + 1), [1, 21, 45]))[~rm]
+    for k, lab in enumerate(np.unique(fac)):
+        pos = np.nonzero(fac == lab)[0]
+        h = dict(hy, a=hy["a"][pos], b=hy["b"][pos])
+        one = locus_core_(Yc, np.asfortranarray(Xs[:, pos]), h, ini["gam_vb"][pos],
+                          ini["mu_beta_vb"][pos], ini["sig2_beta_vb"], ini["tau_vb"], tol=1e-30,
+                          maxit=3, _test_backend=cpu_device)
+        np.testing.assert_array_equal(vb["gam_vb"][pos], one["gam_vb"])
+        assert vb["lb_opt"][k] == one["lb_opt"]
+
+
+def _blocks_worker(rank, world, port, q):
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from locus_amd.comm import DistComm
+        _, _, vb = _blocks_run(DistComm())
+        _, _, ref = _blocks_run(None)
+        np.testing.assert_array_equal(vb["gam_vb"], ref["gam_vb"])
+        np.testing.assert_array_equal(vb["lb_opt"], ref["lb_opt"])
+        dist.destroy_process_group()
+        q.put((rank, None))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e)))
+
+
+def test_locus_blocks_over_ranks_world2_gloo(oracle):
+    """With several ranks block k runs on rank k mod world; every rank ends with all blocks."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_blocks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=60)
+    for rank, err in res:
+        assert err is None, f"rank {rank}: {err}"
