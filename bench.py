@@ -132,8 +132,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; LOCUS_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the
+    # multi-rank path on a one-GPU box (RCCL itself refuses two ranks on one device)
+    backend = os.environ.get("LOCUS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     from locus_amd import device as dv
     from locus_amd.comm import Comm, DistComm
@@ -141,7 +145,10 @@ def main():
     dv.require_gpu()
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         comm = DistComm()
     else:
         comm = Comm()
