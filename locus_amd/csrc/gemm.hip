@@ -6,14 +6,17 @@
 // the logit / probit drivers (R/update_vb.R:107-111,163-167; R/elbo.R:210-237),
 // for which `sqA` squares the A operand on load instead of materialising X^2.
 //
-// Tiling: (32 TW) x (32 TW) block tile, K-tile 16, 4 waves each owning a quadrant as TW x TW MFMA
-// tiles.  LDS is double-buffered: ONE barrier per K-tile, tile t + 1 is written to the other buffer
-// while the MFMAs of tile t read this one and tile t + 2 is in flight from global memory (register
+// Tiling: (32 TW) x (32 TW) block tile, K-tile BK, waves owning a quadrant as TW x TW MFMA tiles.
+// LDS is double-buffered: ONE barrier per K-tile, tile t + 1 is written to the other buffer while
+// the MFMAs of tile t read this one and tile t + 2 is in flight from global memory (register
 // prefetch through running pointers).  LDS rows are padded by 16 doubles so that the two 32-lane
-// halves of a ds_read_b64 fall on disjoint banks.  TW = 2 (64 x 64; 128 registers, 41 KB of LDS:
-// three workgroups per CU) is the shipped tile: measured on MI355X it beats TW = 4 (128 x 128, one
-// workgroup per CU) on every product of the path (scripts/perf_gemm.py: 44.1 vs 29.1 TFLOP/s on
-// the C3 mat_x_m1).  LOCUS_HIP_GEMM_TW=4 selects the large tile for experiments.
+// halves of a ds_read_b64 fall on disjoint banks.  KS = 2: two groups of 4 waves split the k-steps
+// of every K-tile and add their partial tiles through LDS at the end, so that even a workgroup
+// that has its CU to itself runs two waves per SIMD.  Shipped: TW = 2 (64 x 64), KS = 2, BK = 16
+// (74 registers, 41 KB of LDS), BK = 32 when there is at most about one output tile per CU.
+// Measured on MI355X (scripts/perf_gemm.py): 46 TFLOP/s on the C3 mat_x_m1 (TW = 4, 128 x 128,
+// one workgroup per CU: 29 TFLOP/s, kept behind LOCUS_HIP_GEMM_TW=4 for experiments;
+// LOCUS_HIP_GEMM_KS / LOCUS_HIP_GEMM_BK override the other two choices).
 #include <cstdlib>
 
 #include "common.h"
@@ -23,17 +26,20 @@ namespace locus {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16, LDP = 16;
+constexpr int LDP = 16;
 
-template <int TW>
-__global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmDesc g)
+template <int TW, int KS, int BK>
+__global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 {
     constexpr int BM = 32 * TW, BN = 32 * TW;
-    constexpr int NQ = BM * BK / 256;  // elements of each operand tile per thread
-    __shared__ double As[2][BK][BM + LDP];
-    __shared__ double Bs[2][BK][BN + LDP];
+    constexpr int NT = 256 * KS;        // KS groups of 4 waves split the k-steps of every K-tile
+    constexpr int NQ = BM * BK / NT;    // elements of each operand tile per thread
+    constexpr int ASZ = 2 * BK * (BM + LDP), BSZ = 2 * BK * (BN + LDP);
+    __shared__ double lds[ASZ + BSZ];  // one array: the KS == 2 epilogue reuses all of it
+    double (*As)[BK][BM + LDP] = reinterpret_cast<double (*)[BK][BM + LDP]>(lds);
+    double (*Bs)[BK][BN + LDP] = reinterpret_cast<double (*)[BK][BN + LDP]>(lds + ASZ);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
@@ -47,7 +53,7 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmDesc g)
     unsigned okm = 0, okn = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int e = tid + q * 256;
+        const int e = tid + q * NT;
         int am, bn;
         if (a_kfast) { ak[q] = e % BK; am = e / BK; } else { am = e % BM; ak[q] = e / BM; }
         if (b_kfast) { bk[q] = e % BK; bn = e / BK; } else { bn = e % BN; bk[q] = e / BN; }
@@ -100,7 +106,7 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmDesc g)
         if (k0 + BK < g.k) store_tile(buf ^ 1);
         if (k0 + 2 * BK < g.k) load_tile(k0 + 2 * BK);
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
+        for (int kk = 4 * ks; kk < BK; kk += 4 * KS) {
             const int kr = kk + (lane >> 4);
             double a[TW], b[TW];
 #pragma unroll
@@ -115,6 +121,30 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmDesc g)
         }
         __syncthreads();
         buf ^= 1;
+    }
+
+    if constexpr (KS == 2) {
+        // the upper wave group hands its partial tile to the lower one through LDS (As is free:
+        // the loop ended with a barrier)
+        double* xch = lds;
+        static_assert(ASZ + BSZ >= BM * BN, "exchange buffer");
+        const int slot = ((wave * TW * TW) * 4) * 64 + lane;
+        if (ks == 1) {
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xch[slot + ((i * TW + j) * 4 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (ks == 1) return;
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += xch[slot + ((i * TW + j) * 4 + r) * 64];
     }
 
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -139,12 +169,30 @@ int gemm_f64(const GemmDesc& g, hipStream_t st)
 {
     if (g.m <= 0 || g.n <= 0) return 0;
     const char* tw = getenv("LOCUS_HIP_GEMM_TW");
+    const char* ksv = getenv("LOCUS_HIP_GEMM_KS");
     if (tw && tw[0] == '4') {
         dim3 grid((g.m + 127) / 128, (g.n + 127) / 128);
-        hipLaunchKernelGGL(gemm_f64_kernel<4>, grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_f64_kernel<4, 1, 16>), grid, dim3(256), 0, st, g);
     } else {
         dim3 grid((g.m + 63) / 64, (g.n + 63) / 64);
-        hipLaunchKernelGGL(gemm_f64_kernel<2>, grid, dim3(256), 0, st, g);
+        const long tiles = (long)grid.x * grid.y;
+        // few output tiles: a workgroup has its CU to itself, so two wave groups split the
+        // k-steps of every K-tile (two waves per SIMD overlap each other's LDS / barrier latency)
+        const bool split = ksv ? (ksv[0] == '2') : true;
+        const char* bkv = getenv("LOCUS_HIP_GEMM_BK");
+        // at most ~one output tile per CU: the K loop is long and serial, a deeper K-tile halves
+        // its barriers (82 KB of LDS: one workgroup per CU, which is all there is anyway)
+        const bool deep = bkv ? (bkv[0] == '3') : (tiles <= 384);
+        if (split && deep) {
+            auto kern = gemm_f64_kernel<2, 2, 32>;
+            LOCUS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 0));
+            hipLaunchKernelGGL(kern, grid, dim3(512), 0, st, g);
+        } else if (split) {
+            hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 16>), grid, dim3(512), 0, st, g);
+        } else {
+            hipLaunchKernelGGL((gemm_f64_kernel<2, 1, 16>), grid, dim3(256), 0, st, g);
+        }
     }
     LOCUS_HIP_CHECK(hipGetLastError());
     return 0;
