@@ -184,10 +184,13 @@ def main():
 
     perm_rng = np.random.default_rng(1)                   # same stream on every rank
     ev = []
+    nxt = [torch.from_numpy(perm_rng.permutation(p).astype(np.float64)).to(device)]
 
-    def step():
-        ind = perm_rng.permutation(p).astype(np.float64)
-        return eng.iterate(ind, 1.0, with_elbo=True)
+    def draw_next():                                      # on the host while the sweep runs
+        nxt.append(torch.from_numpy(perm_rng.permutation(p).astype(np.float64)).to(device))
+
+    def step():                                           # every step sweeps in a fresh random order
+        return eng.iterate(nxt.pop(0), 1.0, with_elbo=True, after_launch=draw_next)
 
     # kernel timing: HIP events around the sweep launch, on the stream it is launched on
     orig_identity = eng.sweeper.identity

@@ -225,8 +225,10 @@ class IdentityEngine:
         stats = t.cat([cols, rss.reshape(1, d)], dim=0).cpu().numpy()
         self.host.set_initial(stats, rs_gam)
 
-    def iterate(self, shuffled_ind, c=1.0, with_elbo=True):
-        """One pass of the loop body R/locus_core.R:49-211; returns the ELBO (or None)."""
+    def iterate(self, shuffled_ind, c=1.0, with_elbo=True, after_launch=None):
+        """One pass of the loop body R/locus_core.R:49-211; returns the ELBO (or None).
+        `after_launch()` runs on the host once the kernels of this iteration are queued and before
+        the host waits for their statistics (e.g. drawing the next sweep order)."""
         dv = self.dv
         prm = self.host.begin_iteration(c)
         ind = shuffled_ind if self.torch.is_tensor(shuffled_ind) else self._up(shuffled_ind)
@@ -237,7 +239,10 @@ class IdentityEngine:
                                     eps=self.host.ent_eps if with_elbo else None)
         tail = ent.sum().reshape(1) if with_elbo else self.torch.zeros(1, dtype=self.torch.float64,
                                                                       device=self.device)
-        h = self.torch.cat([self.stats.reshape(-1), tail]).cpu().numpy()
+        packed = self.torch.cat([self.stats.reshape(-1), tail])
+        if after_launch is not None:
+            after_launch()
+        h = packed.cpu().numpy()
         self.sweeper.status()
         stats = h[:-1].reshape(4, self.d_loc)
         return self.host.end_iteration(stats, rs_gam, float(h[-1]), c, with_elbo)
@@ -332,13 +337,18 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
         c = float(ladder[0])
 
     converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
+    nxt = {}
     while (not converged) and it < maxit:                                # :49
         lb_old = lb_new
         it += 1
         if verbose and (it == 1 or it % 5 == 0):
             print(f"Iteration {it}... ")
-        ind = np.ascontiguousarray(perm_fn(it), dtype=np.float64)
-        lb = eng.iterate(ind, c, with_elbo=not annealing)
+        ind = nxt.pop(it) if it in nxt else np.ascontiguousarray(perm_fn(it), dtype=np.float64)
+
+        def draw_next(it=it):                                            # overlaps the sweep
+            if it < maxit:
+                nxt[it + 1] = np.ascontiguousarray(perm_fn(it + 1), dtype=np.float64)
+        lb = eng.iterate(ind, c, with_elbo=not annealing, after_launch=draw_next)
         if annealing:                                                    # :177-190
             c = float(ladder[it]) if it < len(ladder) else 1.0
             if np.isclose(c, 1.0, rtol=1.5e-8, atol=0):
