@@ -79,7 +79,10 @@ def make_data(n, p, d, p0, k_lo, k_hi, seed=123):
 
 
 def cpu_baseline(n, d, ncov, seed=7):
-    """Oracle coreLoop (oracle/locus_oracle.c) on `ncov` covariates x all d responses."""
+    """Oracle coreLoop (oracle/locus_oracle.c) on `ncov` covariates x all d responses: the
+    reference's single-threaded path, plus a best-effort all-cores line (the responses are
+    independent, so each thread runs the same routine on its own slice of the columns)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle
     c_oracle.build()
     from locus_amd.simulate import sweep_inputs
@@ -94,10 +97,32 @@ def cpu_baseline(n, d, ncov, seed=7):
     t0 = time.perf_counter()
     _run_oracle(c_oracle, inp)
     dt = time.perf_counter() - t0
+
+    # all cores of this job's CPU share (OMP_NUM_THREADS on the GPU box), same sample again
+    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or os.cpu_count(),
+                       os.cpu_count(), d))
+    inp = sweep_inputs(n, ncov, d, seed=seed)
+    cuts = np.linspace(0, d, cores + 1).astype(int)
+
+    def part(i):
+        k0, k1 = cuts[i], cuts[i + 1]
+        a = dict(inp)
+        for key in ("Y", "gam_vb", "beta_vb", "mat_x_m1", "mu_beta_vb"):
+            a[key] = inp[key][:, k0:k1]          # column slices of Fortran arrays: in place
+        for key in ("log_tau_vb", "sig2_beta_vb", "tau_vb"):
+            a[key] = inp[key][k0:k1]
+        _run_oracle(c_oracle, a)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(part, range(cores)))
+    dt_all = time.perf_counter() - t0
     return dict(value=ncov * d / dt, unit="beta updates/s", cores=1, kind="port",
                 sample=f"oracle coreLoop (gcc -O2, 1 thread) on {ncov} covariates x all {d} "
                        f"responses, n={n} ({dt:.1f} s; cost per covariate does not depend on p); "
-                       f"host has {os.cpu_count()} logical CPUs")
+                       f"host has {os.cpu_count()} logical CPUs",
+                all_cores=dict(value=ncov * d / dt_all, cores=cores,
+                               note=f"same sample, responses split over {cores} threads "
+                                    f"({dt_all:.1f} s)"))
 
 
 def _run_oracle(c_oracle, a):

@@ -1,0 +1,40 @@
+"""Moving the p x d matrices between the host (R's layout: float64, column-major) and a rank's
+[p][d_loc] device planes without extra host passes."""
+import numpy as np
+
+
+def columns_to_device(a, cols, device):
+    """Columns `cols` (slice or index array over the responses) of a p x d matrix as a row-major
+    [p][len(cols)] float64 tensor on `device`.  `a` is a host array, or a
+    locus_amd.prepare.DrawnMatrix, which draws those columns on the device itself."""
+    import torch
+    if hasattr(a, "columns_on"):
+        return a.columns_on(cols, device)
+    a = np.asarray(a, dtype=np.float64)
+    return torch.from_numpy(np.ascontiguousarray(a[:, cols])).to(device)
+
+
+def to_host_F(t):
+    """Row-major [rows][cols] device tensor -> Fortran-ordered numpy (rows x cols); the transpose
+    runs on the device, the host sees one copy."""
+    if t.dim() != 2:
+        return t.cpu().numpy().copy()
+    return t.t().contiguous().cpu().numpy().T
+
+
+class LazyFields(dict):
+    """Fields of a driver's result that are downloaded on first use: locus() only needs gam_vb and
+    beta_vb unless full_output is set (R/locus_core.R:242-252)."""
+
+    def __init__(self, **makers):
+        super().__init__()
+        self._makers = makers
+
+    def __missing__(self, key):
+        v = self[key] = self._makers[key]()
+        return v
+
+    def all(self):
+        for k in self._makers:
+            self[k]
+        return dict(self)

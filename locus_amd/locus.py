@@ -9,8 +9,8 @@ asking for them raises NotImplementedError rather than silently doing something 
 """
 import numpy as np
 
-from .prepare import (add_intercept_, auto_set_hyper_, auto_set_init_, convert_p0_av_,
-                      prepare_data_, scale_rm_)
+from .prepare import (add_intercept_, auto_set_hyper_, auto_set_init_, auto_set_init_drawn_,
+                      convert_p0_av_, prepare_data_, scale_rm_)
 
 
 def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, list_init=None,
@@ -73,8 +73,10 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
     else:
         list_hyper = dict(list_hyper)
     if list_init is None:
-        list_init = auto_set_init_(Y, p, p_star, q=q, user_seed=user_seed, link=link,
-                                   ind_bin=ind_bin)
+        # the p x d initial matrices are drawn by each rank on its GPU (prepare.DrawnMatrix);
+        # the block-wise path slices them by rows on the host, so it keeps the host draw
+        draw = auto_set_init_ if vec_fac_bl is not None else auto_set_init_drawn_
+        list_init = draw(Y, p, p_star, q=q, user_seed=user_seed, link=link, ind_bin=ind_bin)
     else:
         list_init = dict(list_init)
     if link != "identity":

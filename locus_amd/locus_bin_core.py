@@ -23,6 +23,7 @@ from scipy.special import digamma
 from . import elbo as E
 from . import update_vb as U
 from .comm import Comm
+from .hostio import LazyFields, columns_to_device, to_host_F
 from .locus_core import EPS_MACH, HostBase, _gather, resolve_backend
 
 
@@ -114,7 +115,7 @@ class BinEngine:
         self.D = torch.empty((p, d), dtype=f64, device=device)
         self.sweeper = dv.Sweeper(px, d, device)
         if link == "logit":
-            self.s2 = torch.from_numpy(np.ascontiguousarray(sig2_beta_vb, dtype=np.float64)).to(device)
+            self.s2 = sig2_beta_vb if torch.is_tensor(sig2_beta_vb) else self._up(sig2_beta_vb)
             assert tuple(self.s2.shape) == (p, d)
             self.xwx = torch.empty((p, d), dtype=f64, device=device)
             self.s2a = self._up(np.ascontiguousarray(sig2_alpha_vb, dtype=np.float64).reshape(q, d))
@@ -239,16 +240,15 @@ class BinEngine:
         return host.finish_elbo(float(tot[0]), fn)
 
     def download(self):
-        out = {}
-        for name, qq in (("gam_vb", 0), ("mu_beta_vb", 1), ("beta_vb", 2)):
-            out[name] = self.state[qq].cpu().numpy().copy(order="F")
-        out["mat_x_m1"] = self.M.cpu().numpy().copy(order="F")
-        out["mat_z_mu"] = self.Zmu.cpu().numpy().copy(order="F")
-        out["alpha_vb"] = self.alpha.cpu().numpy().copy()
+        out = LazyFields(gam_vb=lambda: to_host_F(self.state[0]),
+                         mu_beta_vb=lambda: to_host_F(self.state[1]),
+                         beta_vb=lambda: to_host_F(self.state[2]),
+                         mat_x_m1=lambda: to_host_F(self.M), mat_z_mu=lambda: to_host_F(self.Zmu),
+                         alpha_vb=lambda: self.alpha.cpu().numpy().copy())
         if self.link == "logit":
-            out["sig2_beta_vb"] = self.s2.cpu().numpy().copy(order="F")
-            out["psi_vb"] = (self.W2[self.cur] / 2).cpu().numpy().copy(order="F")
-            out["chi_vb"] = self.chi[self.cur].cpu().numpy().copy(order="F")
+            out._makers.update(sig2_beta_vb=lambda: to_host_F(self.s2),
+                               psi_vb=lambda: to_host_F(self.W2[self.cur] / 2),
+                               chi_vb=lambda: to_host_F(self.chi[self.cur]))
         else:
             out["sig2_beta_vb"] = self.s2c
         return out
@@ -275,12 +275,12 @@ def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
     px = dv.PackedX(dv.to_device_colmajor(X, device))
     Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
     state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)
-    state[0] = torch.from_numpy(np.ascontiguousarray(np.asarray(gam_vb)[:, k_lo:k_hi])).to(device)
-    state[1] = torch.from_numpy(np.ascontiguousarray(np.asarray(mu_beta_vb)[:, k_lo:k_hi])).to(device)
+    state[0] = columns_to_device(gam_vb, slice(k_lo, k_hi), device)
+    state[1] = columns_to_device(mu_beta_vb, slice(k_lo, k_hi), device)
     alpha_loc = np.asarray(alpha_vb, dtype=np.float64).reshape(q, d)[:, k_lo:k_hi]
     if link == "logit":
         s2a_loc = np.asarray(sig2_alpha_vb, dtype=np.float64).reshape(q, d)[:, k_lo:k_hi]
-        s2b_loc = np.asarray(sig2_beta_vb, dtype=np.float64)[:, k_lo:k_hi]
+        s2b_loc = columns_to_device(sig2_beta_vb, slice(k_lo, k_hi), device)
     else:
         s2a_loc, s2b_loc = sig2_alpha_vb, float(sig2_beta_vb)
     eng = BinEngine(link, px, Y_dev, Z, state, alpha_loc, s2a_loc, s2b_loc, host, device, dv=dv)

@@ -17,6 +17,7 @@ from scipy.special import digamma
 from . import elbo as E
 from . import update_vb as U
 from .comm import Comm
+from .hostio import LazyFields, columns_to_device, to_host_F
 
 EPS_SQRT = np.finfo(np.float64).eps ** 0.5  # R/locus_core.R:31
 EPS_MACH = np.finfo(np.float64).eps         # R/elbo.R:46
@@ -248,14 +249,12 @@ class IdentityEngine:
         return self.host.end_iteration(stats, rs_gam, float(h[-1]), c, with_elbo)
 
     def download(self):
-        """gam_vb, mu_beta_vb, beta_vb (p x d_loc) and mat_x_m1 (n x d_loc) as numpy, R layout."""
-        dv = self.dv
-        out = {}
-        for name, q in (("gam_vb", 0), ("mu_beta_vb", 1), ("beta_vb", 2)):
-            out[name] = self.state[q].cpu().numpy().copy(order="F")
-        M = dv.residual(self.Y, self.R)  # M = Y - R
-        out["mat_x_m1"] = M.cpu().numpy().copy(order="F")
-        return out
+        """gam_vb, mu_beta_vb, beta_vb (p x d_loc) and mat_x_m1 (n x d_loc) as numpy, R layout;
+        each is fetched when first asked for."""
+        return LazyFields(gam_vb=lambda: to_host_F(self.state[0]),
+                          mu_beta_vb=lambda: to_host_F(self.state[1]),
+                          beta_vb=lambda: to_host_F(self.state[2]),
+                          mat_x_m1=lambda: to_host_F(self.dv.residual(self.Y, self.R)))  # M = Y - R
 
 
 def resolve_backend(test_backend, device):
@@ -325,8 +324,8 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
     px = dv.PackedX(dv.to_device_colmajor(X, device))
     Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
     state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)
-    state[0] = torch.from_numpy(np.ascontiguousarray(np.asarray(gam_vb)[:, k_lo:k_hi])).to(device)
-    state[1] = torch.from_numpy(np.ascontiguousarray(np.asarray(mu_beta_vb)[:, k_lo:k_hi])).to(device)
+    state[0] = columns_to_device(gam_vb, slice(k_lo, k_hi), device)
+    state[1] = columns_to_device(mu_beta_vb, slice(k_lo, k_hi), device)
     eng = IdentityEngine(px, Y_dev, state, host, device, dv=dv)
     eng.initialise()
 

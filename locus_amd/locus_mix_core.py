@@ -14,6 +14,7 @@ from scipy.special import digamma
 from . import elbo as E
 from . import update_vb as U
 from .comm import Comm
+from .hostio import LazyFields, columns_to_device, to_host_F
 from .locus_core import IdentityEngine, IdentityHost, _gather, _gather_vec, resolve_backend
 
 
@@ -189,12 +190,11 @@ class MixEngine(IdentityEngine):
                                        h[4 * d + 1:], ey_bin, self.zz)
 
     def download(self):
-        out = {}
-        for name, qq in (("gam_vb", 0), ("mu_beta_vb", 1), ("beta_vb", 2)):
-            out[name] = self.state[qq].cpu().numpy().copy(order="F")
-        out["mat_x_m1"] = self.M.cpu().numpy().copy(order="F")
-        out["mat_z_mu"] = self.Zmu.cpu().numpy().copy(order="F")
-        out["alpha_vb"] = self.alpha.cpu().numpy().copy()
+        out = LazyFields(gam_vb=lambda: to_host_F(self.state[0]),
+                         mu_beta_vb=lambda: to_host_F(self.state[1]),
+                         beta_vb=lambda: to_host_F(self.state[2]),
+                         mat_x_m1=lambda: to_host_F(self.M), mat_z_mu=lambda: to_host_F(self.Zmu),
+                         alpha_vb=lambda: self.alpha.cpu().numpy().copy())
         return out
 
 
@@ -242,8 +242,8 @@ def locus_mix_core_(Y, X, Z, ind_bin, list_hyper, gam_vb, alpha_vb, mu_beta_vb, 
     px = dv.PackedX(dv.to_device_colmajor(X, device))
     Y_dev = dv.to_device_colmajor(Y[:, order], device)
     state = torch.empty((3, p, len(order)), dtype=torch.float64, device=device)
-    state[0] = torch.from_numpy(np.ascontiguousarray(np.asarray(gam_vb)[:, order])).to(device)
-    state[1] = torch.from_numpy(np.ascontiguousarray(np.asarray(mu_beta_vb)[:, order])).to(device)
+    state[0] = columns_to_device(gam_vb, order, device)
+    state[1] = columns_to_device(mu_beta_vb, order, device)
     eng = MixEngine(px, Y_dev, Z, state, host, device, dv=dv)
     eng.initialise()
 

@@ -11,6 +11,7 @@ from scipy.special import log_ndtr
 from . import elbo as E
 from . import update_vb as U
 from .comm import Comm
+from .hostio import LazyFields, columns_to_device, to_host_F
 from .locus_core import HostBase, IdentityEngine, _gather, _gather_vec, resolve_backend
 from .struct import StructBlocks, row_sums_W_struct_
 
@@ -121,8 +122,8 @@ def locus_struct_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_v
     px = dv.PackedX(dv.to_device_colmajor(X, device))
     Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
     state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)
-    state[0] = torch.from_numpy(np.ascontiguousarray(np.asarray(gam_vb)[:, k_lo:k_hi])).to(device)
-    state[1] = torch.from_numpy(np.ascontiguousarray(np.asarray(mu_beta_vb)[:, k_lo:k_hi])).to(device)
+    state[0] = columns_to_device(gam_vb, slice(k_lo, k_hi), device)
+    state[1] = columns_to_device(mu_beta_vb, slice(k_lo, k_hi), device)
     eng = IdentityEngine(px, Y_dev, state, host, device, dv=dv)
     eng.initialise()
 

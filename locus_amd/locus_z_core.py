@@ -16,6 +16,7 @@ from scipy.special import digamma
 from . import elbo as E
 from . import update_vb as U
 from .comm import Comm
+from .hostio import LazyFields, columns_to_device, to_host_F
 from .locus_core import (EPS_SQRT, IdentityEngine, IdentityHost, _gather, _gather_vec,
                          resolve_backend)
 
@@ -171,12 +172,11 @@ class ZEngine(IdentityEngine):
         return self.host.end_iteration(stats, rs_gam, float(h[4 * d]), h[4 * d + 1:], c, with_elbo)
 
     def download(self):
-        out = {}
-        for name, qq in (("gam_vb", 0), ("mu_beta_vb", 1), ("beta_vb", 2)):
-            out[name] = self.state[qq].cpu().numpy().copy(order="F")
-        out["mat_x_m1"] = self.M.cpu().numpy().copy(order="F")
-        out["mat_z_mu"] = self.Zmu.cpu().numpy().copy(order="F")
-        out["alpha_vb"] = self.alpha.cpu().numpy().copy()
+        out = LazyFields(gam_vb=lambda: to_host_F(self.state[0]),
+                         mu_beta_vb=lambda: to_host_F(self.state[1]),
+                         beta_vb=lambda: to_host_F(self.state[2]),
+                         mat_x_m1=lambda: to_host_F(self.M), mat_z_mu=lambda: to_host_F(self.Zmu),
+                         alpha_vb=lambda: self.alpha.cpu().numpy().copy())
         return out
 
 
@@ -217,8 +217,8 @@ def locus_z_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_
     px = dv.PackedX(dv.to_device_colmajor(X, device))
     Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
     state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)
-    state[0] = torch.from_numpy(np.ascontiguousarray(np.asarray(gam_vb)[:, k_lo:k_hi])).to(device)
-    state[1] = torch.from_numpy(np.ascontiguousarray(np.asarray(mu_beta_vb)[:, k_lo:k_hi])).to(device)
+    state[0] = columns_to_device(gam_vb, slice(k_lo, k_hi), device)
+    state[1] = columns_to_device(mu_beta_vb, slice(k_lo, k_hi), device)
     eng = ZEngine(px, Y_dev, Z, state, alpha_loc, host, device, dv=dv)
     eng.initialise()
 

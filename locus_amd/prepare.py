@@ -16,13 +16,36 @@ def scale_rm_(X):
         Xs = (X - X.mean(axis=0)) / X.std(axis=0, ddof=1)
     bool_cst = np.isnan(Xs.sum(axis=0))                       # rm_constant_
     Xs = Xs[:, ~bool_cst]
-    _, first = np.unique(Xs, axis=1, return_index=True)       # rm_collinear_: keep first copies
-    bool_coll = np.ones(Xs.shape[1], dtype=bool)
-    bool_coll[first] = False
+    bool_coll = _duplicated_columns(Xs)                       # rm_collinear_: keep first copies
     Xs = Xs[:, ~bool_coll]
     bool_rmvd = bool_cst.copy()
     bool_rmvd[~bool_cst] = bool_coll
     return Xs, bool_rmvd
+
+
+def _duplicated_columns(Xs):
+    """duplicated(Xs, MARGIN = 2) (R/utils.R:283): mask of the columns equal to an earlier one.
+    One exact 64-bit hash per column (wrapping integer dot product of the bit patterns with fixed
+    odd multipliers), then an exact comparison inside each group of equal hashes -- O(n p) instead
+    of a lexicographic sort of the columns."""
+    n, p = Xs.shape
+    bits = np.ascontiguousarray(Xs + 0.0).view(np.uint64)     # + 0.0: -0.0 and 0.0 compare equal
+    mult = np.random.default_rng(0x10C05).integers(1, 2 ** 63, size=n, dtype=np.uint64) * 2 + 1
+    with np.errstate(over="ignore"):
+        h = mult @ bits
+    order = np.argsort(h, kind="stable")
+    hs = h[order]
+    dup = np.zeros(p, dtype=bool)
+    start = np.nonzero(np.r_[True, hs[1:] != hs[:-1]])[0]
+    stop = np.r_[start[1:], p]
+    for a, b in zip(start[stop - start > 1], stop[stop - start > 1]):
+        kept = []
+        for j in order[a:b]:                                  # ascending column index
+            if any(np.array_equal(Xs[:, j], Xs[:, k]) for k in kept):
+                dup[j] = True
+            else:
+                kept.append(j)
+    return dup
 
 
 def prepare_data_(Y, X, link="identity", ind_bin=None):
@@ -161,6 +184,88 @@ def auto_set_init_(Y, p, p_star, q=None, user_seed=None, link="identity", ind_bi
             init["sig2_alpha_vb"] = 1.0 / rng.gamma(2.0, rng.gamma(1.0, 1.0, size=q))
     else:
         init["alpha_vb"] = init["sig2_alpha_vb"] = None
+    return init
+
+
+class DrawnMatrix:
+    """A p x d matrix of independent draws that is never materialised on the host: every rank
+    draws the columns of its own response shard directly on its GPU (at C3 the two p x d initial
+    matrices are 4 GB each; numpy needs ~15 s to draw them and PCIe ~1 s to move them, the CAVI
+    iterations to convergence take 0.5 s).
+
+    The columns come in chunks of CHUNK responses, each from its own generator seeded with
+    (seed, kind, chunk), so the values do not depend on how the responses are sharded.
+    kind: "beta1"  Beta(1, param) by inversion, param a scalar or one value per row
+                   (gam_vb, R/set_hyper_init.R:765);
+          "normal" N(0, 1) (mu_beta_vb, :780);
+          "inv_gamma2" 1 / Gamma(shape 2, scale param) (logit sig2_beta_vb, :811).
+    np.asarray(m) materialises the matrix (column-major) for host-side callers."""
+    CHUNK = 256
+    KINDS = ("beta1", "normal", "inv_gamma2")
+
+    def __init__(self, kind, p, d, seed=None, param=None):
+        assert kind in self.KINDS
+        self.kind, self.shape, self.param = kind, (int(p), int(d)), param
+        ss = seed if isinstance(seed, np.random.SeedSequence) else np.random.SeedSequence(seed)
+        self.seed = int(ss.generate_state(1, dtype=np.uint64)[0])
+        self.ndim, self.dtype = 2, np.dtype(np.float64)
+
+    def _chunk(self, c, device):
+        import torch
+        p, d = self.shape
+        w = min(self.CHUNK, d - c * self.CHUNK)
+        key = np.random.SeedSequence([self.seed, self.KINDS.index(self.kind), c])
+        g = torch.Generator(device=device)
+        g.manual_seed(int(key.generate_state(1, dtype=np.uint64)[0] >> np.uint64(1)))
+        kw = dict(generator=g, dtype=torch.float64, device=device)
+        if self.kind == "normal":
+            return torch.randn((p, w), **kw)
+        lu = torch.log1p(-torch.rand((p, w), **kw))           # log of a uniform on (0, 1]
+        if self.kind == "beta1":                                # 1 - U^(1/b)
+            b = torch.as_tensor(self.param, dtype=torch.float64, device=device).reshape(-1, 1)
+            return -torch.expm1(lu / b)
+        lu += torch.log1p(-torch.rand((p, w), **kw))          # Gamma(2) = -log(U1 U2)
+        return 1.0 / (-float(self.param) * lu).clamp_min(1e-300)
+
+    def columns_on(self, cols, device):
+        """[p][len(cols)] row-major float64 tensor on `device`; cols: slice or index array."""
+        import torch
+        p, d = self.shape
+        cols = np.arange(d)[cols]
+        out = torch.empty((p, len(cols)), dtype=torch.float64, device=device)
+        which = cols // self.CHUNK
+        for c in np.unique(which):
+            pos = np.nonzero(which == c)[0]
+            blk = self._chunk(int(c), device)
+            src = cols[pos] - c * self.CHUNK
+            if len(pos) == blk.shape[1] and pos[-1] - pos[0] == len(pos) - 1 \
+                    and np.array_equal(src, np.arange(len(pos))):
+                out[:, pos[0]:pos[-1] + 1] = blk
+            else:
+                out[:, torch.as_tensor(pos, device=device)] = blk[:, torch.as_tensor(src, device=device)]
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        import torch
+        dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        from .hostio import to_host_F
+        return to_host_F(self.columns_on(slice(None), dev))
+
+
+def auto_set_init_drawn_(Y, p, p_star, q=None, user_seed=None, link="identity", ind_bin=None):
+    """auto_set_init_ with the p x d matrices (gam_vb, mu_beta_vb, logit sig2_beta_vb) left as
+    DrawnMatrix recipes for the drivers to draw on their GPUs; everything else as auto_set_init_."""
+    d = Y.shape[1]
+    # the small fields (tau_vb, sig2_beta_vb of length d, alpha_vb, ...) from the host routine,
+    # called with a single stand-in covariate
+    init = auto_set_init_(Y, 1, 0.5, q=q, user_seed=user_seed, link=link, ind_bin=ind_bin)
+    ss = np.random.SeedSequence(user_seed).spawn(3)
+    shape2 = d * (p - np.asarray(p_star, dtype=np.float64)) / p_star
+    init["p_init"] = p
+    init["gam_vb"] = DrawnMatrix("beta1", p, d, ss[0], shape2)
+    init["mu_beta_vb"] = DrawnMatrix("normal", p, d, ss[1])
+    if link == "logit":
+        init["sig2_beta_vb"] = DrawnMatrix("inv_gamma2", p, d, ss[2], init["sig2_inv_vb"])
     return init
 
 

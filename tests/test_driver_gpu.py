@@ -275,3 +275,34 @@ def test_locus_entry_point_on_gpu(hip):
     found = (vb["gam_vb"] > 0.5).any(axis=1)
     assert found[sim["ind_p0"]].mean() >= 0.8 and found.sum() <= 2 * len(sim["ind_p0"])
     assert len(vb["rmvd_x"]) == 0 and vb["om_vb"].shape == (500,)
+
+
+def test_default_initial_values_drawn_on_the_gpu(hip, oracle):
+    """locus() draws its default p x d initial matrices on the GPU (prepare.DrawnMatrix): a shard's
+    values do not depend on the sharding, the same seed gives the same fit, and the fit from those
+    values equals the numpy restatement of the driver started from the same (downloaded) values."""
+    import torch
+    from oracle.ref_driver import locus_core_ as ref_core
+    from locus_amd import locus
+    from locus_amd.prepare import (auto_set_hyper_, auto_set_init_drawn_, prepare_data_)
+    from locus_amd.locus_core import locus_core_
+    from locus_amd.simulate import simulate
+    sim = simulate(150, 300, 700, 10, seed=5)
+    Yc, Xs, _ = prepare_data_(sim["Y"], sim["X"])
+    ini = auto_set_init_drawn_(Yc, 300, 10, user_seed=9)
+    dev = torch.device("cuda", 0)
+    full = np.asarray(ini["gam_vb"])
+    np.testing.assert_array_equal(ini["gam_vb"].columns_on(slice(200, 613), dev).cpu().numpy(),
+                                  full[:, 200:613])
+    a = locus(sim["Y"], sim["X"], p0_av=10, user_seed=9, tol=1e-30, maxit=3, verbose=False)
+    b = locus(sim["Y"], sim["X"], p0_av=10, user_seed=9, tol=1e-30, maxit=3, verbose=False)
+    np.testing.assert_array_equal(a["gam_vb"], b["gam_vb"])
+    hy = auto_set_hyper_(Yc, 300, 10)
+    perms = [np.random.default_rng(40 + i).permutation(300).astype(np.float64) for i in range(3)]
+    kw = dict(tol=1e-30, maxit=3, perm_fn=lambda it: perms[it - 1])
+    got = locus_core_(Yc, Xs, hy, ini["gam_vb"], ini["mu_beta_vb"], ini["sig2_beta_vb"],
+                      ini["tau_vb"], **kw)
+    ref = ref_core(Yc, Xs, hy, full.copy(order="F"), np.asarray(ini["mu_beta_vb"]).copy(order="F"),
+                   ini["sig2_beta_vb"], ini["tau_vb"], **kw)
+    np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], rtol=1e-9, atol=1e-300)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])

@@ -98,6 +98,82 @@ def test_locus_block_wise_equals_per_block_fits(oracle):
         assert vb["lb_opt"][k] == one["lb_opt"]
 
 
+def test_duplicated_columns_match_lexicographic_unique():
+    """prepare._duplicated_columns (hash + exact check) against numpy's sort-based unique, the
+    semantics of R's duplicated(X, MARGIN = 2): every copy after the first is flagged."""
+    from locus_amd.prepare import _duplicated_columns, scale_rm_
+    rng = np.random.default_rng(8)
+    X = rng.binomial(2, 0.3, size=(40, 900)).astype(np.float64)     # short columns: many repeats
+    X[:, 700] = X[:, 2]
+    X[:, 30] = 0.0
+    X[:, 31] = -0.0                                                 # equal to column 30
+    dup = _duplicated_columns(X)
+    _, first = np.unique(X + 0.0, axis=1, return_index=True)
+    ref = np.ones(X.shape[1], dtype=bool)
+    ref[first] = False
+    np.testing.assert_array_equal(dup, ref)
+    assert dup[700] and dup[31] and not dup[2] and not dup[30]
+    Xs, rm = scale_rm_(X)
+    assert rm[30] and rm[31] and rm[700] and Xs.shape[1] == X.shape[1] - rm.sum()
+
+
+def test_drawn_initial_values():
+    """prepare.DrawnMatrix: the default p x d initial matrices are drawn per response chunk, so
+    a rank's shard does not depend on the sharding; distributions as R/set_hyper_init.R:765,780,811."""
+    import torch
+    from locus_amd.prepare import DrawnMatrix, auto_set_init_drawn_
+    cpu = torch.device("cpu")
+    m = DrawnMatrix("beta1", 400, 600, 5, 50.0)
+    full = np.asarray(m)
+    assert full.shape == (400, 600) and full.flags.f_contiguous
+    assert abs(full.mean() - 1 / 51) < 2e-4 and full.min() >= 0 and full.max() < 1
+    np.testing.assert_array_equal(m.columns_on(slice(100, 333), cpu).numpy(), full[:, 100:333])
+    idx = np.array([5, 599, 256, 3, 511])
+    np.testing.assert_array_equal(m.columns_on(idx, cpu).numpy(), full[:, idx])
+    np.testing.assert_array_equal(np.asarray(DrawnMatrix("beta1", 400, 600, 5, 50.0)), full)
+    assert not np.array_equal(np.asarray(DrawnMatrix("beta1", 400, 600, 6, 50.0)), full)
+    rows = np.asarray(DrawnMatrix("beta1", 3, 4000, 1, np.array([1.0, 9.0, 99.0])))
+    np.testing.assert_allclose(rows.mean(axis=1), [0.5, 0.1, 0.01], rtol=0.08)
+    z = np.asarray(DrawnMatrix("normal", 300, 400, 2))
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    g = np.asarray(DrawnMatrix("inv_gamma2", 300, 400, 2, 1e-2))
+    assert abs(np.median(1 / g) / (1e-2 * 1.67835) - 1) < 0.02      # median of Gamma(2, scale)
+    Y = np.random.default_rng(0).normal(size=(50, 7))
+    ini = auto_set_init_drawn_(Y, 30, 3, q=2, user_seed=4, link="logit")
+    assert all(isinstance(ini[k], DrawnMatrix) for k in ("gam_vb", "mu_beta_vb", "sig2_beta_vb"))
+    assert ini["alpha_vb"].shape == (2, 7) and ini["sig2_alpha_vb"].shape == (2, 7)
+    ini = auto_set_init_drawn_(Y, 30, 3, user_seed=4)
+    assert ini["sig2_beta_vb"].shape == (7,) and ini["tau_vb"].shape == (7,)
+
+
+def _default_init_worker(rank, world, port, q):
+    """locus() with its default (drawn) initial values: responses sharded over two ranks give the
+    single-rank result (the draw does not depend on the sharding; sums differ in association)."""
+    try:
+        import torch
+        import torch.distributed as dist
+        import cpu_device
+        from locus_amd.locus import locus
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from locus_amd.comm import DistComm
+        for link in ("identity", "logit"):
+            sim, X = _data(link)
+            kw = dict(link=link, user_seed=11, tol=1e-30, maxit=3, verbose=False,
+                      full_output=True, _test_backend=cpu_device)
+            two = locus(sim["Y"], X, P0, comm=DistComm(), **kw)
+            one = locus(sim["Y"], X, P0, **kw)
+            for key in ("gam_vb", "mu_beta_vb", "beta_vb"):
+                np.testing.assert_allclose(two[key], one[key], rtol=1e-9, atol=1e-300)
+            assert abs(two["lb_opt"] - one["lb_opt"]) <= 1e-8 * abs(one["lb_opt"])
+        dist.destroy_process_group()
+        q.put((rank, None))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e)))
+
+
 def _blocks_worker(rank, world, port, q):
     try:
         import torch
@@ -117,8 +193,10 @@ def _blocks_worker(rank, world, port, q):
         q.put((rank, traceback.format_exc() + repr(e)))
 
 
-def test_locus_blocks_over_ranks_world2_gloo(oracle):
-    """With several ranks block k runs on rank k mod world; every rank ends with all blocks."""
+@pytest.mark.parametrize("worker", ["blocks", "default_init"])
+def test_locus_over_ranks_world2_gloo(oracle, worker):
+    """blocks: with several ranks block k runs on rank k mod world, every rank ends with all
+    blocks.  default_init: see _default_init_worker."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -126,7 +204,8 @@ def test_locus_blocks_over_ranks_world2_gloo(oracle):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_blocks_worker, args=(r, 2, port, q)) for r in range(2)]
+    target = dict(blocks=_blocks_worker, default_init=_default_init_worker)[worker]
+    procs = [ctx.Process(target=target, args=(r, 2, port, q)) for r in range(2)]
     for pr in procs:
         pr.start()
     res = [q.get(timeout=240) for _ in procs]
