@@ -14,12 +14,27 @@ def columns_to_device(a, cols, device):
     return torch.from_numpy(np.ascontiguousarray(a[:, cols])).to(device)
 
 
+def _to_host(t):
+    """Device tensor -> host tensor through a page-locked destination: 57 GB/s measured on the
+    MI355X box against 4 GB/s into pageable memory (scripts/perf_d2h.py).  The numpy array handed
+    to the caller lives in that page-locked block."""
+    import torch
+    if t.device.type == "cpu":                 # test backend: never alias the engine's buffers
+        return t.clone()
+    try:
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    except RuntimeError:                       # no page-locked memory left: plain copy
+        return t.cpu()
+    h.copy_(t)
+    return h
+
+
 def to_host_F(t):
     """Row-major [rows][cols] device tensor -> Fortran-ordered numpy (rows x cols); the transpose
     runs on the device, the host sees one copy."""
     if t.dim() != 2:
-        return t.cpu().numpy().copy()
-    return t.t().contiguous().cpu().numpy().T
+        return _to_host(t.contiguous()).numpy().copy()
+    return _to_host(t.t().contiguous()).numpy().T
 
 
 class LazyFields(dict):
