@@ -48,7 +48,6 @@ int download(double* host, const DevMem& m, size_t count)
 int check_dims(int64_t n, int64_t p, int64_t d)
 {
     LOCUS_REQUIRE(n >= 1 && p >= 1 && d >= 1, "n, p and d must be >= 1");
-    LOCUS_REQUIRE(n <= 2048, "n > 2048 rows is not supported by the register-resident sweep");
     LOCUS_REQUIRE(p < (1ll << 31) && d < (1ll << 31) && n * d < (1ll << 40) && p * d < (1ll << 40),
                   "problem too large");
     return 0;
@@ -174,6 +173,7 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
     prm.R = a->R;
     prm.state = a->state;
     prm.st = a->stats;
+    if (cfg.NPL == -2) return run_stream_sweep(prm, logit != 0, st);
     if (cfg.NPL < 0) {
         LOCUS_REQUIRE(!logit, "sweep: the matrix-core kernel covers the identity family only");
         return run_mfma_sweep(prm, cfg, ws.xb, mfma_workspace_bytes(a->n, a->p), st);

@@ -89,6 +89,9 @@ bool mfma_sweep_covers(int n);
 int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
                    hipStream_t st);
 int launch_sweep(const SweepParams& prm, const SweepConfig& cfg, bool logit, hipStream_t stream);
+// NPL == -2 selects the streaming kernel (stream_sweep.hip): any n, both families; what the
+// chooser falls back to when n exceeds the register-resident kernels.
+int run_stream_sweep(const SweepParams& prm, bool logit, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepConfig& cfg);
 
 }  // namespace locus

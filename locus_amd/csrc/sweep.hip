@@ -79,7 +79,7 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
     if (const char* env = getenv("LOCUS_HIP_SWEEP_CFG")) {  // "NPL,C,S,G" (tuning / tests)
         SweepConfig c{};
         if (sscanf(env, "%d,%d,%d,%d", &c.NPL, &c.C, &c.S, &c.G) == 4 &&
-            (c.NPL < 0 ? !logit : (c.NPL * c.S * 64 >= n))) {
+            (c.NPL == -2 || (c.NPL < 0 ? !logit : (c.NPL * c.S * 64 >= n)))) {
             *out = c;
             return 0;
         }
@@ -138,10 +138,7 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
             }
         }
     }
-    if (bc.NPL == 0) {
-        set_error("sweep: n is too large for the register-resident kernel (n <= 2048)");
-        return LOCUS_HIP_EUNSUPPORTED;
-    }
+    if (bc.NPL == 0) bc = SweepConfig{-2, 0, 0, 0};  // n > 2048: the streaming kernel
     *out = bc;
     return 0;
 }

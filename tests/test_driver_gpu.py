@@ -306,3 +306,29 @@ def test_default_initial_values_drawn_on_the_gpu(hip, oracle):
                    ini["sig2_beta_vb"], ini["tau_vb"], **kw)
     np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], rtol=1e-9, atol=1e-300)
     assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+
+
+def test_drivers_with_more_than_2048_samples(oracle, hip):
+    """n above the register-resident kernels (streaming sweep kernel) through whole drivers:
+    identity and logit, two iterations against the numpy restatements."""
+    from oracle import ref_driver
+    from locus_amd import locus_bin_core
+    from locus_amd.locus_core import locus_core_
+    sim, hyper, init, perm_fn = _setup(n=2300, p=40, d=6, p0=4, seed=21)
+    kw = dict(tol=1e-30, maxit=2, perm_fn=perm_fn, full_output=True)
+    args = (sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"], init["sig2_beta_vb"],
+            init["tau_vb"])
+    ref, got = ref_driver.locus_core_(*args, **kw), locus_core_(*args, **kw)
+    for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+
+    sim, hyper, init, Z, perm_fn, aperm_fn = _setup_bin("logit", n=2100, p=30, d=5, p0=4)
+    args = (sim["Y"], sim["X"], Z, hyper, init["gam_vb"], init["alpha_vb"], init["mu_beta_vb"],
+            init["sig2_alpha_vb"], init["sig2_beta_vb"])
+    kw = dict(tol=1e-30, maxit=2, perm_fn=perm_fn, alpha_perm_fn=aperm_fn)
+    ref = ref_driver.locus_logit_core_(*args, **kw)
+    got = locus_bin_core.locus_logit_core_(*args, full_output=True, **kw)
+    for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1", "alpha_vb"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])

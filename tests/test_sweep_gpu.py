@@ -123,14 +123,43 @@ def test_mfma_planned_multi_launch(oracle, hip, variant, monkeypatch):
     assert_parity(got, ref, what=f"{variant} planned multi-launch")
 
 
-@pytest.mark.parametrize("vector", [False, True])
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("shape", [(200, 90, 7), (3, 5, 2), (257, 33, 1), (513, 20, 4)])
+def test_streaming_kernel_forced(oracle, hip, variant, shape, monkeypatch):
+    """stream_sweep_kernel (the fallback for n beyond the register-resident kernels) on shapes the
+    other kernels also cover: every variant, ragged rows, n < one wave."""
+    n, p, d = shape
+    inp = inputs_for(variant, n, p, d, seed=n + d)
+    ref = call_variant(oracle, variant, inp)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", "-2,0,0,0")
+    got = call_variant(hip, variant, inp)
+    assert_parity(got, ref, what=f"{variant} streaming {shape}")
+
+
+@pytest.mark.parametrize("variant,n", [("identity", 2049), ("struct", 3000), ("z", 2500),
+                                       ("probit", 4100), ("logit", 2100), ("logit", 8000),
+                                       ("identity", 16001)])
+def test_more_than_2048_samples(oracle, hip, variant, n, monkeypatch):
+    """No limit on n: above 2048 rows (2016 for the matrix-core kernel) the library picks the
+    streaming kernel by itself -- residual column in LDS up to 120 KB (n <= 15 359; logit, which
+    also keeps the 2 psi column: n <= 7679), in global memory beyond."""
+    monkeypatch.delenv("LOCUS_HIP_SWEEP_CFG", raising=False)
+    inp = inputs_for(variant, n, 24, 5, seed=n)
+    ref = call_variant(oracle, variant, inp)
+    got = call_variant(hip, variant, inp)
+    assert_parity(got, ref, what=f"{variant} n={n}")
+
+
+@pytest.mark.parametrize("vector", [False, True, "stream"])
 def test_partial_sweeps_compose(hip, vector, monkeypatch):
     """nsteps < p (locus_hip_sweep_args.nsteps): visiting the first k covariates of the order and
     then the remaining p - k equals one full sweep, on the resident state (both kernels)."""
     import torch
     from locus_amd import device as dv
     monkeypatch.delenv("LOCUS_HIP_SWEEP_CFG", raising=False)
-    if vector:
+    if vector == "stream":
+        monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", "-2,0,0,0")
+    elif vector:
         monkeypatch.setenv("LOCUS_HIP_SWEEP_VECTOR", "1")
     n, p, d, k = 150, 77, 21, 30
     dev = torch.device("cuda:0")
