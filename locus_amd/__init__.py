@@ -14,6 +14,9 @@ from .core import (coreBatch, coreLogitLoop, coreLoop, coreProbitBatch,  # noqa:
                    coreProbitLoop, coreStructLoop, coreZBatch, coreZLoop)
 
 from .locus import locus  # noqa: F401,E402
+from .cross_validate import set_cv  # noqa: F401,E402
+from .prepare import set_blocks  # noqa: F401,E402
+from .struct import set_struct  # noqa: F401,E402
 
-__all__ = ["locus", "coreLoop", "coreZLoop", "coreLogitLoop", "coreProbitLoop", "coreStructLoop",
+__all__ = ["locus", "set_cv", "set_blocks", "set_struct", "coreLoop", "coreZLoop", "coreLogitLoop", "coreProbitLoop", "coreStructLoop",
            "coreBatch", "coreZBatch", "coreProbitBatch"]

@@ -3,9 +3,11 @@ paths rebuilt here.  Prepares the data (standardisation, constant / duplicated c
 default hyper-parameters and initial values when none are given, dispatches on link / Z /
 list_struct to the device-resident drivers and returns the reference's `vb` fields.
 
-Not rebuilt (out of scope): cross-validation (list_cv) and group selection
-(list_groups);
-asking for them raises NotImplementedError rather than silently doing something else.
+`list_cv` (set_cv): p0_av is chosen by cross-validation on the held-out ELBO
+(locus_amd.cross_validate, R/cross_validate.R) for the identity link.
+
+Not rebuilt (out of scope): group selection (list_groups); asking for it raises
+NotImplementedError rather than silently doing something else.
 """
 import numpy as np
 
@@ -19,9 +21,8 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
           checkpoint_path=None, comm=None, device=None, _test_backend=None):
     """Arguments and return fields as R/locus.R:240-245, :605-640 (`comm`: response sharding over
     the GPUs of a node, see locus_amd.comm; every rank passes the full arrays)."""
-    for name, v in (("list_cv", list_cv), ("list_groups", list_groups)):
-        if v is not None:
-            raise NotImplementedError(f"{name} is outside the rebuilt path (SURVEY.md §8)")
+    if list_groups is not None:
+        raise NotImplementedError("list_groups is outside the rebuilt path (SURVEY.md §8)")
     if link not in ("identity", "logit", "probit", "mix"):
         raise ValueError("link must be 'identity', 'logit', 'probit' or 'mix'")
     if (link == "mix") != (ind_bin is not None):             # R/prepare_locus.R:769-785
@@ -63,7 +64,15 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
         vec_fac_bl = np.asarray(list_blocks["vec_fac_bl"])[~bool_rmvd_x]
         n_bl = len(np.unique(vec_fac_bl))
     p_star = None
-    if list_hyper is None or list_init is None:
+    if list_cv is not None and list_blocks is None and list_struct is None:  # R/locus.R:280-292
+        from .cross_validate import cross_validate_, prepare_cv_
+        if verbose:
+            print("===== Cross-validation... =====")
+        list_cv = prepare_cv_(list_cv, n, p, bool_rmvd_x, p0_av, link, list_hyper, list_init,
+                              verbose)
+        p_star = cross_validate_(Y, X, Z, link, ind_bin, list_cv, user_seed, verbose, comm=comm,
+                                 device=device, _test_backend=_test_backend)
+    elif list_hyper is None or list_init is None:
         p_star = convert_p0_av_(p0_av, len(bool_rmvd_x), n_bl)
         if np.ndim(p_star) > 0:
             p_star = p_star[~bool_rmvd_x]
@@ -91,6 +100,8 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
                                             full_output=full_output, comm=comm, device=device,
                                             _test_backend=_test_backend))
     vb["p_star"] = p_star
+    if list_cv is not None and "lb_mat" in list_cv:
+        vb["cv_lb_mat"] = list_cv["lb_mat"]                      # held-out ELBO, folds x grid
     vb["rmvd_x"] = np.nonzero(bool_rmvd_x)[0]                    # R/locus.R:620-626
     vb["rmvd_z"] = None if bool_rmvd_z is None else np.nonzero(bool_rmvd_z)[0]
     return vb

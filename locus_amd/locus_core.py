@@ -99,6 +99,22 @@ class IdentityHost(HostBase):
         a_vb, b_vb = self.a_vb, self.b_vb
         return a_vb / (a_vb + b_vb)
 
+    def held_out_elbo_(self, n_test, rss_test):
+        """The ELBO of the last iteration re-evaluated with the held-out rows' n and residual
+        sums of squares, everything else (gam_vb, m2_beta, tau_vb, sig2_inv_vb, ...) as fitted:
+        what elbo_(Y_test, ..., mat_x_m1 = X_test %*% beta_vb, ...) computes."""
+        n_fit, st_fit = self.n, self.stats
+        try:
+            self.n = int(n_test)
+            st = st_fit.copy()
+            st[3] = rss_test
+            return self._end_again(st)
+        finally:
+            self.n, self.stats = n_fit, st_fit
+
+    def _end_again(self, stats):
+        return self.end_iteration(stats, *self._last)
+
     def _omega_terms(self):
         """Covariate-wise terms of the ELBO at c = 1 (R/locus_core.R:270-275; R/elbo.R:43-54,
         114-118), evaluated where rowSums(gam) lives; two scalars come back:
@@ -162,6 +178,7 @@ class IdentityHost(HostBase):
     def end_iteration(self, stats, rs_gam_local, ent_local, c=1.0, with_elbo=True):
         n, d = self.n, self.d
         self.stats = np.asarray(stats, dtype=np.float64)
+        self._last = (rs_gam_local, ent_local)
         cs_gam, cs_m2, cs_b2, rss = self.stats
         tau, s2, si = self.tau_vb, self.sig2_beta_vb, self.sig2_inv_vb
         t_loc = float(tau @ cs_m2)
@@ -190,6 +207,19 @@ class IdentityHost(HostBase):
 
 class IdentityEngine:
     """One GPU's shard of the identity-link model."""
+
+    def held_out_elbo(self, Y_test_loc, X_test, Zmu_test=None):
+        """elbo_ with the fitted variational parameters on held-out rows (R/cross_validate.R:
+        313-322): mat_x_m1 = X_test beta_vb on the matrix cores, the residual sum of squares per
+        response, then the host's ELBO with n = nrow(Y_test)."""
+        t, dv = self.torch, self.dv
+        nt, p, d = Y_test_loc.shape[0], self.p, self.d_loc
+        Xt = dv.to_device_colmajor(X_test, self.device)
+        Yt = dv.to_device_colmajor(Y_test_loc, self.device)
+        M = t.empty((d, nt), dtype=t.float64, device=self.device).t()
+        dv.gemm(nt, d, p, Xt, 1, nt, self.state[2], d, 1, M, 1, nt)
+        R = dv.residual(Yt, M, Zmu_test)
+        return self.host.held_out_elbo_(nt, (R * R).sum(dim=0).cpu().numpy())
 
     def __init__(self, px, Y_dev, state, host, device, cfg=None, dv=None):
         import torch
@@ -288,8 +318,11 @@ def checkpoint_clean_up_(checkpoint_path):  # R/utils.R:339-352
 def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol, maxit,
                 anneal=None, verbose=False, batch="y", full_output=False, debug=True,
                 checkpoint_path=None, perm_fn=None, comm=None, device=None, trace=None,
-                _test_backend=None):
+                held_out=None, _test_backend=None):
     """R/locus_core.R:8-255 on the GPU.  Y (n x d) must be centred and X (n x p) standardised.
+
+    `held_out = (Y_test, X_test)` adds `lb_held_out`, the ELBO of the fit on those rows (the
+    cross-validation objective, R/cross_validate.R:313-322).
 
     `perm_fn(it)` supplies the sweep order of iteration `it` (float64, 0-based); by default
     numpy draws it (R: sample(0:(p-1)), :88).  With a DistComm every rank passes the FULL
@@ -371,6 +404,9 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
     out = dict(beta_vb=_gather(comm, loc["beta_vb"], d), gam_vb=_gather(comm, loc["gam_vb"], d),
                om_vb=host.om_vb, converged=converged, it=it, lb_opt=lb_new,
                diff_lb=abs(lb_new - lb_old), annealing=False if anneal is None else anneal[0])
+    if held_out is not None:
+        Yt = np.asarray(held_out[0], dtype=np.float64)
+        out["lb_held_out"] = eng.held_out_elbo(Yt[:, k_lo:k_hi], held_out[1])
     if full_output:                                                      # :242-247
         out.update(mu_beta_vb=_gather(comm, loc["mu_beta_vb"], d),
                    mat_x_m1=_gather(comm, loc["mat_x_m1"], d),

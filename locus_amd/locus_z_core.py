@@ -85,6 +85,7 @@ class ZHost(IdentityHost):
     def end_iteration(self, stats, rs_gam_local, ent_local, alpha_vb, c=1.0, with_elbo=True):
         n, d, q = self.n, self.d, self.q
         self.stats = np.asarray(stats, dtype=np.float64)
+        self._last = (rs_gam_local, ent_local, alpha_vb)
         cs_gam, cs_m2, cs_b2, rss = self.stats
         alpha_vb = np.asarray(alpha_vb, dtype=np.float64).reshape(q, -1)
         self.m2_alpha = U.update_m2_alpha_(alpha_vb, self.sig2_alpha_vb)
@@ -171,6 +172,11 @@ class ZEngine(IdentityEngine):
         stats = h[: 4 * d].reshape(4, d)
         return self.host.end_iteration(stats, rs_gam, float(h[4 * d]), h[4 * d + 1:], c, with_elbo)
 
+    def held_out_elbo_z(self, Y_test_loc, X_test, Z_test):
+        """elbo_z_ on held-out rows (R/cross_validate.R:331-343): mat_z_mu = Z_test alpha_vb."""
+        Zmu = self._up((np.asarray(Z_test, dtype=np.float64) @ self.alpha.cpu().numpy()).T).t()
+        return self.held_out_elbo(Y_test_loc, X_test, Zmu)
+
     def download(self):
         out = LazyFields(gam_vb=lambda: to_host_F(self.state[0]),
                          mu_beta_vb=lambda: to_host_F(self.state[1]),
@@ -183,10 +189,11 @@ class ZEngine(IdentityEngine):
 def locus_z_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb, sig2_beta_vb,
                   tau_vb, tol, maxit, anneal=None, verbose=False, batch="y", full_output=False,
                   debug=True, perm_fn=None, alpha_perm_fn=None, comm=None, device=None, trace=None,
-                  _test_backend=None):
+                  held_out=None, _test_backend=None):
     """R/locus_z_core.R:8-290 on the GPU.  Y (n x d) centred, X (n x p) and Z (n x q) standardised.
     Arguments as locus_core_ plus the covariate block; `alpha_perm_fn(it)` supplies the order of
-    the alpha loop (R: sample(1:q), :96), 0-based."""
+    the alpha loop (R: sample(1:q), :96), 0-based.  `held_out = (Y_test, X_test, Z_test)` adds
+    `lb_held_out` (R/cross_validate.R:331-343)."""
     dv, device = resolve_backend(_test_backend, device)
     import torch
     if batch != "y":
@@ -257,6 +264,9 @@ def locus_z_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_
                om_vb=host.om_vb, alpha_vb=_gather(comm, loc["alpha_vb"], d), converged=converged,
                it=it, lb_opt=lb_new, diff_lb=abs(lb_new - lb_old),
                annealing=False if anneal is None else anneal[0])
+    if held_out is not None:
+        Yt = np.asarray(held_out[0], dtype=np.float64)
+        out["lb_held_out"] = eng.held_out_elbo_z(Yt[:, k_lo:k_hi], held_out[1], held_out[2])
     if full_output:                                                      # :267-274
         out.update(mu_beta_vb=_gather(comm, loc["mu_beta_vb"], d),
                    mat_x_m1=_gather(comm, loc["mat_x_m1"], d),

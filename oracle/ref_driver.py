@@ -1102,3 +1102,64 @@ def sweep_identity_scalar_R(X, Y, gam_vb, log_om_vb, log_1_min_om_vb, log_sig2_i
             - mu ** 2 / (2 * sig2_beta_vb) - np.log(sig2_beta_vb) / 2)))  # :148-151
         beta_vb[j, :] = mu_beta_vb[j, :] * gam_vb[j, :]                 # :153
         mat_x_m1 += np.outer(xj, beta_vb[j, :])                         # :155
+
+
+# --------------------------------------------------------------------------- #
+# R/cross_validate.R
+# --------------------------------------------------------------------------- #
+def cross_validate_(Y, X, Z, list_cv, set_hyper_init, perm_fn):
+    """R/cross_validate.R:177-418 for link = "identity" (full matrices, folds one after the
+    other).  `set_hyper_init(Y_tr, p, pg, q)` returns (list_hyper, list_init) -- the defaults of
+    R/set_hyper_init.R, whose random draws the caller controls.  Returns (p0_av_opt, lb_mat)."""
+    n, d = Y.shape
+    grid = np.asarray(list_cv["p0_av_grid"], dtype=np.float64)
+    n_folds = list_cv["n_folds"]
+    folds = np.arange(n) % n_folds                                       # :189
+    lb_mat = np.zeros((n_folds, len(grid)))
+
+    def scale_pair(A_tr, A_test):                                        # :200-209
+        with np.errstate(invalid="ignore", divide="ignore"):
+            S = (A_tr - A_tr.mean(axis=0)) / A_tr.std(axis=0, ddof=1)
+        keep = ~np.isnan(S.sum(axis=0))
+        return S[:, keep], A_test[:, keep]
+
+    for k in range(n_folds):
+        cur = folds == k
+        X_tr, X_test = scale_pair(X[~cur], X[cur])
+        p = X_tr.shape[1]
+        Y_tr = Y[~cur] - Y[~cur].mean(axis=0)                            # :214-215
+        Y_test = Y[cur] - Y[cur].mean(axis=0)
+        q = None
+        if Z is not None:
+            Z_tr, Z_test = scale_pair(Z[~cur], Z[cur])
+            q = Z_tr.shape[1]
+        for g, pg in enumerate(grid):
+            hy, li = set_hyper_init(Y_tr, p, pg, q)
+            kw = dict(tol=list_cv["tol_cv"], maxit=list_cv["maxit_cv"], perm_fn=perm_fn)
+            a, b = np.broadcast_to(hy["a"], (p,)), np.broadcast_to(hy["b"], (p,))
+            if q is None:                                                # :303-322
+                vb = locus_core_(Y_tr, X_tr, hy, li["gam_vb"].copy(), li["mu_beta_vb"].copy(),
+                                 li["sig2_beta_vb"], li["tau_vb"], full_output=True, **kw)
+                rs = vb["gam_vb"].sum(axis=1)
+                lb_mat[k, g] = elbo_(
+                    Y_test, a, update_a_vb(a, rs), b, update_b_vb(b, d, rs), vb["beta_vb"],
+                    hy["eta"], vb["gam_vb"], hy["kappa"], hy["lambda"], hy["nu"],
+                    vb["sig2_beta_vb"], vb["sig2_inv_vb"], vb["tau_vb"], vb["m2_beta"],
+                    X_test @ vb["beta_vb"], vb["sum_gam"])
+            else:                                                        # :323-343
+                vb = locus_z_core_(Y_tr, X_tr, Z_tr, hy, li["gam_vb"].copy(), li["alpha_vb"].copy(),
+                                   li["mu_beta_vb"].copy(), li["sig2_alpha_vb"], li["sig2_beta_vb"],
+                                   li["tau_vb"], **kw)
+                rs = vb["gam_vb"].sum(axis=1)
+                m2_beta = update_m2_beta_(vb["gam_vb"], vb["mu_beta_vb"], vb["sig2_beta_vb"],
+                                          sweep=True)
+                m2_alpha = update_m2_alpha_(vb["alpha_vb"], vb["sig2_alpha_vb"])
+                phi = np.broadcast_to(np.asarray(hy["phi"], dtype=np.float64), (q,))
+                xi = np.broadcast_to(np.asarray(hy["xi"], dtype=np.float64), (q,))
+                lb_mat[k, g] = elbo_z_(
+                    Y_test, Z_test, a, update_a_vb(a, rs), b, update_b_vb(b, d, rs), vb["beta_vb"],
+                    hy["eta"], vb["gam_vb"], hy["kappa"], hy["lambda"], vb["alpha_vb"], hy["nu"],
+                    phi, update_phi_z_vb_(phi, d), vb["sig2_alpha_vb"], vb["sig2_beta_vb"],
+                    vb["sig2_inv_vb"], vb["tau_vb"], xi, vb["zeta2_inv_vb"], m2_alpha, m2_beta,
+                    X_test @ vb["beta_vb"], Z_test @ vb["alpha_vb"], float(vb["gam_vb"].sum()))
+    return float(grid[int(np.argmax(lb_mat.mean(axis=0)))]), lb_mat

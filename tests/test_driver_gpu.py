@@ -332,3 +332,35 @@ def test_drivers_with_more_than_2048_samples(oracle, hip):
     for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1", "alpha_vb"):
         np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
     assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+
+
+@pytest.mark.parametrize("with_z", [False, True])
+def test_cross_validation_on_gpu(oracle, hip, with_z):
+    """cross_validate_ (R/cross_validate.R:177-418) on the device: the held-out lower bounds of
+    every fold and grid value against the full-matrix restatement, then locus(list_cv = ...)."""
+    from oracle import ref_driver
+    from locus_amd import locus
+    from locus_amd.cross_validate import cross_validate_, set_cv
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_, prepare_data_
+    from locus_amd.simulate import simulate
+    n, p, d = 150, 120, 12
+    sim = simulate(n, p, d, 8, seed=31)
+    Yc, Xs, _ = prepare_data_(sim["Y"], sim["X"])
+    Z = np.random.default_rng(3).normal(size=(n, 2)) if with_z else None
+    cv = set_cv(n, p, n_folds=3, size_p0_av_grid=3, maxit_cv=4, verbose=False)
+    cv["p0_av_grid"], cv["tol_cv"] = np.array([4.0, 10.0, 30.0]), 1e-30
+    perms = {}
+
+    def perm_fn(it):
+        return perms.setdefault(it, np.random.default_rng(70 + it).permutation(p).astype(np.float64))
+
+    def defaults(Y_tr, pp, pg, q):
+        return (auto_set_hyper_(Y_tr, pp, pg, q=q), auto_set_init_(Y_tr, pp, pg, q=q, user_seed=5))
+    ref_opt, ref_lb = ref_driver.cross_validate_(Yc, Xs, Z, cv, defaults, perm_fn)
+    got_opt = cross_validate_(Yc, Xs, Z, "identity", None, cv, 5, False, perm_fn=perm_fn,
+                              alpha_perm_fn=lambda it: np.arange(2))
+    np.testing.assert_allclose(cv["lb_mat"], ref_lb, rtol=1e-8)
+    assert got_opt == ref_opt
+    cv = set_cv(n, p, n_folds=2, size_p0_av_grid=2, tol_cv=1.0, maxit_cv=5, verbose=False)
+    vb = locus(sim["Y"], sim["X"], None, Z=Z, list_cv=cv, user_seed=5, maxit=3, verbose=False)
+    assert vb["p_star"] in cv["p0_av_grid"] and vb["cv_lb_mat"].shape == (2, len(cv["p0_av_grid"]))

@@ -55,7 +55,7 @@ def test_locus_refuses_what_is_out_of_scope(oracle):
     import cpu_device
     from locus_amd.locus import locus
     sim, X = _data()
-    for kw in (dict(list_cv={}), dict(list_groups={})):
+    for kw in (dict(list_groups={}),):
         with pytest.raises(NotImplementedError):
             locus(sim["Y"], X, P0, _test_backend=cpu_device, verbose=False, **kw)
     with pytest.raises(ValueError):
@@ -96,6 +96,46 @@ def test_locus_block_wise_equals_per_block_fits(oracle):
                           maxit=3, _test_backend=cpu_device)
         np.testing.assert_array_equal(vb["gam_vb"][pos], one["gam_vb"])
         assert vb["lb_opt"][k] == one["lb_opt"]
+
+
+@pytest.mark.parametrize("with_z", [False, True])
+def test_cross_validation_matches_restatement(oracle, with_z):
+    """cross_validate_ (R/cross_validate.R:177-418): held-out lower bounds of every fold and grid
+    value against the full-matrix restatement; then locus(list_cv = ...) end to end."""
+    import cpu_device
+    from oracle import ref_driver
+    from locus_amd.cross_validate import create_grid_, cross_validate_, set_cv
+    from locus_amd.locus import locus
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_, prepare_data_
+    np.testing.assert_array_equal(create_grid_(60, 3), [15, 18, 20])      # R: round(seq(15, 20, l = 3))
+    np.testing.assert_array_equal(create_grid_(2000, 4), [500, 675, 825, 1000])
+    np.testing.assert_array_equal(create_grid_(100, 5), [25, 50])         # base 25, duplicates dropped
+    sim, X = _data()
+    Yc, Xs, _ = prepare_data_(sim["Y"], X)
+    Z = np.random.default_rng(3).normal(size=(N, 2)) if with_z else None
+    cv = set_cv(N, X.shape[1], n_folds=3, size_p0_av_grid=3, maxit_cv=3, verbose=False)
+    cv["p0_av_grid"], cv["tol_cv"] = np.array([3.0, 8.0, 20.0]), 1e-30   # exactly 3 iterations
+    perms = {}
+
+    def perm_fn(it):
+        p = 60
+        return perms.setdefault(it, np.random.default_rng(70 + it).permutation(p).astype(np.float64))
+
+    def defaults(Y_tr, p, pg, q):
+        return (auto_set_hyper_(Y_tr, p, pg, q=q), auto_set_init_(Y_tr, p, pg, q=q, user_seed=5))
+    ref_opt, ref_lb = ref_driver.cross_validate_(Yc, Xs, Z, cv, defaults, perm_fn)
+    got_opt = cross_validate_(Yc, Xs, Z, "identity", None, cv, 5, False, _test_backend=cpu_device,
+                              perm_fn=perm_fn, alpha_perm_fn=lambda it: np.arange(2))
+    np.testing.assert_allclose(cv["lb_mat"], ref_lb, rtol=1e-8)
+    assert got_opt == ref_opt and cv["lb_mat"].shape == (3, 3)
+    assert len(set(np.round(ref_lb.mean(axis=0), 3))) == 3                 # the grid matters
+
+    cv = set_cv(N, X.shape[1], n_folds=2, size_p0_av_grid=2, tol_cv=1.0, maxit_cv=5, verbose=False)
+    vb = locus(sim["Y"], X, None, Z=Z, list_cv=cv, user_seed=5, tol=1e-30, maxit=2, verbose=False,
+               _test_backend=cpu_device)
+    assert vb["p_star"] in cv["p0_av_grid"] and vb["cv_lb_mat"].shape == (2, len(cv["p0_av_grid"]))
+    with pytest.raises(ValueError):                                        # p0_av must be None
+        locus(sim["Y"], X, 5, list_cv=cv, verbose=False, _test_backend=cpu_device)
 
 
 def test_duplicated_columns_match_lexicographic_unique():
@@ -174,6 +214,37 @@ def _default_init_worker(rank, world, port, q):
         q.put((rank, traceback.format_exc() + repr(e)))
 
 
+def _cv_worker(rank, world, port, q):
+    """Cross-validation with the folds spread over two ranks gives the single-rank matrix."""
+    try:
+        import torch
+        import torch.distributed as dist
+        import cpu_device
+        from locus_amd.cross_validate import cross_validate_, set_cv
+        from locus_amd.prepare import prepare_data_
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from locus_amd.comm import DistComm
+        sim, X = _data()
+        Yc, Xs, _ = prepare_data_(sim["Y"], X)
+        perm_fn = lambda it: np.random.default_rng(70 + it).permutation(60).astype(np.float64)  # noqa: E731
+        res = []
+        for comm in (DistComm(), None):
+            cv = set_cv(N, X.shape[1], n_folds=3, size_p0_av_grid=2, tol_cv=1.0, maxit_cv=3,
+                        verbose=False)
+            opt = cross_validate_(Yc, Xs, None, "identity", None, cv, 5, False, comm=comm,
+                                  _test_backend=cpu_device, perm_fn=perm_fn)
+            res.append((opt, cv["lb_mat"]))
+        assert res[0][0] == res[1][0]
+        np.testing.assert_array_equal(res[0][1], res[1][1])
+        dist.destroy_process_group()
+        q.put((rank, None))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e)))
+
+
 def _blocks_worker(rank, world, port, q):
     try:
         import torch
@@ -193,7 +264,7 @@ def _blocks_worker(rank, world, port, q):
         q.put((rank, traceback.format_exc() + repr(e)))
 
 
-@pytest.mark.parametrize("worker", ["blocks", "default_init"])
+@pytest.mark.parametrize("worker", ["blocks", "default_init", "cv"])
 def test_locus_over_ranks_world2_gloo(oracle, worker):
     """blocks: with several ranks block k runs on rank k mod world, every rank ends with all
     blocks.  default_init: see _default_init_worker."""
@@ -204,7 +275,7 @@ def test_locus_over_ranks_world2_gloo(oracle, worker):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    target = dict(blocks=_blocks_worker, default_init=_default_init_worker)[worker]
+    target = dict(blocks=_blocks_worker, default_init=_default_init_worker, cv=_cv_worker)[worker]
     procs = [ctx.Process(target=target, args=(r, 2, port, q)) for r in range(2)]
     for pr in procs:
         pr.start()
