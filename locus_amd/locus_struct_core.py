@@ -6,21 +6,24 @@ involves theta (W, the block matvecs, e_theta_) needs only rowSums(gam_vb), so i
 replicated host arithmetic on the all-reduced vector.
 """
 import numpy as np
-from scipy.special import log_ndtr
 
 from . import elbo as E
 from . import update_vb as U
 from .comm import Comm
 from .hostio import LazyFields, columns_to_device, to_host_F
 from .locus_core import HostBase, IdentityEngine, _gather, _gather_vec, resolve_backend
-from .struct import StructBlocks, row_sums_W_struct_
+from .struct import LOG_SQRT_2PI, StructBlocks
 
 EPS_STRUCT = np.finfo(np.float64).eps ** 0.75  # R/elbo.R:94
 
 
 class StructHost(HostBase):
     """Replicated / shard-local vector arithmetic of locus_struct_core_
-    (R/locus_struct_core.R:51-145).  Same interface as IdentityHost."""
+    (R/locus_struct_core.R:51-145).  Same interface as IdentityHost.
+
+    Everything of length p -- theta_vb, log Phi(theta_vb), rowSums(W), the per-block products with
+    S0_inv and sig2_theta_vb (80 MB of matrices at C5, read once per iteration) -- lives on the
+    device that holds the all-reduced rowSums(gam_vb); only scalars come back to the host."""
 
     ent_eps = EPS_STRUCT
 
@@ -32,18 +35,60 @@ class StructHost(HostBase):
         self.lam, self.nu = float(hyper["lambda"]), float(hyper["nu"])
         self.m0 = np.asarray(hyper["m0"], dtype=np.float64)
         self.blocks = blocks
-        self.theta_vb = self.m0.copy()                             # :25
         self.tau_vb = np.array(tau_vb, dtype=np.float64)
         self.sig2_beta_vb = np.array(sig2_beta_vb, dtype=np.float64)
         self.sig2_inv_vb = None
-        self.rs_gam = self.sum_gam = self.sum_tau_m2 = None
+        self.sum_gam = self.sum_tau_m2 = None
         self.stats = None
+        self.rs_gam_t = self.theta_t = self._lp = None
+
+    # -- length-p state on the device ---------------------------------------------------------
+    def _on_device(self, dev):
+        import torch
+        if self.theta_t is not None and self.theta_t.device == dev:
+            return
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.m0_t = up(self.m0)
+        self.theta_t = self.m0_t.clone()                           # :25
+        self._lp = None
+        self.groups_t = [(up(pos.astype(np.int64)), up(S), up(V)) for pos, S, V in self.blocks.groups]
+        self.S_m0_t = torch.empty_like(self.m0_t)                  # S0_inv_bl m0_bl, constant
+        for pos, S, _ in self.groups_t:
+            self.S_m0_t[pos] = torch.bmm(S, self.m0_t[pos].unsqueeze(-1)).squeeze(-1)
+
+    @property
+    def theta_vb(self):
+        return self.theta_t.cpu().numpy()
+
+    @property
+    def rs_gam(self):
+        return self.rs_gam_t.cpu().numpy()
+
+    def _reduce(self, rs_gam_local, scalars):
+        """ONE all-reduce of [rowSums(gam) (p) | scalars]; rowSums stays on its device."""
+        import torch
+        self._on_device(rs_gam_local.device)
+        tail = torch.as_tensor(np.asarray(scalars, dtype=np.float64).reshape(-1),
+                               device=rs_gam_local.device)
+        buf = torch.cat([rs_gam_local.reshape(-1), tail])
+        self.comm.all_reduce_sum_(buf)
+        self.rs_gam_t = buf[: self.p]
+        return buf[self.p:]
+
+    def _log_phi(self):
+        """log Phi(theta_vb), log(1 - Phi(theta_vb)): needed by the sweep, by W and by the ELBO;
+        evaluated once per value of theta_vb."""
+        import torch
+        if self._lp is None:
+            self._lp = (torch.special.log_ndtr(self.theta_t), torch.special.log_ndtr(-self.theta_t))
+        return self._lp
 
     def set_initial(self, stats, rs_gam_local):
+        import torch
         self.stats = np.asarray(stats, dtype=np.float64)
-        self.rs_gam, sc = self._all_reduce(rs_gam_local, [float(self.tau_vb @ self.stats[1])])
-        self.sum_gam = float(self.rs_gam.sum())
-        self.sum_tau_m2 = float(sc[0])
+        sc = self._reduce(rs_gam_local, [float(self.tau_vb @ self.stats[1])])
+        h = torch.cat([sc, self.rs_gam_t.sum().reshape(1)]).cpu().numpy()
+        self.sum_tau_m2, self.sum_gam = float(h[0]), float(h[1])
 
     def begin_iteration(self, c=1.0):                                     # :60-84
         assert c == 1.0, "annealing is not available for the structured model"
@@ -59,11 +104,13 @@ class StructHost(HostBase):
         log_tau_vb = U.update_log_tau_vb_(eta_vb, kappa_vb)
         log_sig2_inv_vb = U.update_log_sig2_inv_vb_(lambda_vb, nu_vb)
         s2 = self.sig2_beta_vb
-        return dict(lo=log_ndtr(self.theta_vb), l1=log_ndtr(-self.theta_vb), c=1.0,
+        lp, l1p = self._log_phi()
+        return dict(lo=lp, l1=l1p, c=1.0,
                     scale=s2 * self.tau_vb, hinv=1.0 / (2.0 * s2),
                     cst=-(log_tau_vb + log_sig2_inv_vb + np.log(s2)) / 2, s2k=s2)
 
     def end_iteration(self, stats, rs_gam_local, ent_local, c=1.0, with_elbo=True):
+        import torch
         n, d = self.n, self.d
         self.stats = np.asarray(stats, dtype=np.float64)
         cs_gam, cs_m2, cs_b2, rss = self.stats
@@ -75,21 +122,39 @@ class StructHost(HostBase):
         loc = (E.e_y_(n, self.kappa, kappa_vb, log_tau_vb, cs_m2, si, tau)
                + E.e_beta_gamma_local_(cs_gam, cs_m2, ent_local, log_tau_vb, s2, si, tau)
                + E.e_tau_(self.eta, eta_vb, self.kappa, kappa_vb, log_tau_vb, tau))
-        self.rs_gam, sc = self._all_reduce(rs_gam_local, [float(tau @ cs_m2), loc])
-        self.sum_tau_m2 = float(sc[0])
-        self.sum_gam = float(self.rs_gam.sum())
-        # W and theta (:127-129): only rowSums(W) enters
-        rs_W = row_sums_W_struct_(self.rs_gam, d, self.theta_vb)
-        self.theta_vb = self.blocks.update_theta_vb_(rs_W, self.m0)
-        # replicated part of elbo_struct_, with the NEW theta_vb (:132-135)
+        sc = self._reduce(rs_gam_local, [float(tau @ cs_m2), loc])
+        rs, th = self.rs_gam_t, self.theta_t
+        # W and theta (:127-129): only rowSums(W) enters, W_jk = gam_jk (imr1_j - imr0_j) +
+        # theta_j + imr0_j with the inverse Mills ratios of R/utils.R:201-220
+        lp, l1p = self._log_phi()
+        dens = -th * th / 2 - LOG_SQRT_2PI
+        imr0 = -torch.exp(dens - l1p)
+        imr0 = torch.where(imr0 > -th, -th, imr0)
+        imr1 = torch.exp(dens - lp)
+        imr1 = torch.where(imr1 < -th, -th, imr1)
+        x = (imr1 - imr0) * rs + d * (th + imr0) + self.S_m0_t
+        # theta_bl = sig2_theta_bl (rowSums(W_bl) + S0_inv_bl m0_bl)  (R/update_vb.R:315-319)
+        theta = torch.empty_like(th)
+        for pos, _, V in self.groups_t:
+            theta[pos] = torch.bmm(V, x[pos].unsqueeze(-1)).squeeze(-1)
+        self.theta_t, self._lp = theta, None
+        lp, l1p = self._log_phi()                                         # of the NEW theta_vb
+        # replicated part of elbo_struct_, with the NEW theta_vb (:132-135; R/elbo.R:98-104,
+        # 166-180)
+        dlt = theta - self.m0_t
+        quad = torch.zeros((), dtype=torch.float64, device=th.device)
+        for pos, S, _ in self.groups_t:
+            db = dlt[pos]
+            quad = quad + (db * torch.bmm(S, db.unsqueeze(-1)).squeeze(-1)).sum()
+        h = torch.cat([sc, torch.stack([rs.sum(), (rs * lp).sum() + ((d - rs) * l1p).sum(),
+                                        quad])]).cpu().numpy()
+        self.sum_tau_m2, self.sum_gam = float(h[0]), float(h[2])
         lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam)
         nu_vb = U.update_nu_vb_(self.nu, self.sum_tau_m2)
         log_sig2_inv_vb = U.update_log_sig2_inv_vb_(lambda_vb, nu_vb)
-        glob = (log_sig2_inv_vb * self.sum_gam / 2
-                + np.sum(self.rs_gam * log_ndtr(self.theta_vb))
-                + np.sum((d - self.rs_gam) * log_ndtr(-self.theta_vb))
-                - d * np.sum(self.blocks.diag_sig2_theta) / 2)            # R/elbo.R:98-104
-        return float(sc[1] + glob + self.blocks.e_theta_(self.m0, self.theta_vb)
+        glob = (log_sig2_inv_vb * self.sum_gam / 2 + float(h[3])
+                - d * self.blocks.sum_diag_sig2_theta / 2)
+        return float(h[1] + glob + self.blocks.e_theta_const - float(h[4]) / 2
                      + E.e_sig2_inv_(self.lam, lambda_vb, log_sig2_inv_vb, self.nu, nu_vb, si))
 
 

@@ -138,21 +138,39 @@ class StructBlocks:
         self.diag_sig2_theta = np.concatenate([np.diag(V) for V in self.sig2_theta])
         self.trace_SV = np.array([np.sum(S * V) for S, V in zip(self.S0_inv, self.sig2_theta)])
         assert self.diag_sig2_theta.size == p
+        # blocks of equal size stacked for the per-iteration products (one batched matmul per
+        # size instead of a Python loop over hundreds of blocks): positions [nb][b], S, V [nb][b][b]
+        self.groups = []
+        for b, ids in by_size.items():
+            pos = np.array([self.slices[i][0] for i in ids])[:, None] + np.arange(b)[None, :]
+            self.groups.append((pos, np.stack([self.S0_inv[i] for i in ids]),
+                                np.stack([self.sig2_theta[i] for i in ids])))
+        # e_theta_ = e_theta_const - sum_bl (theta - m0)' S0_inv (theta - m0) / 2
+        self.e_theta_const = float(np.sum(self.sum_log_det) - np.sum(self.trace_SV) + p) / 2
+        self.sum_diag_sig2_theta = float(np.sum(self.diag_sig2_theta))
+        self._S_m0 = (None, None)
 
     def update_theta_vb_(self, rs_W, m0):
         """R/update_vb.R:315-319: theta_bl = sig2_theta_bl (rowSums(W_bl) + S0_inv_bl m0_bl)."""
+        if self._S_m0[0] is not m0:                                        # constant over the run
+            sm = np.empty_like(m0)
+            for pos, S, _ in self.groups:
+                sm[pos] = np.matmul(S, m0[pos][:, :, None])[:, :, 0]
+            self._S_m0 = (m0, sm)
+        x = rs_W + self._S_m0[1]
         theta = np.empty_like(rs_W)
-        for (lo, hi), S, V in zip(self.slices, self.S0_inv, self.sig2_theta):
-            theta[lo:hi] = V @ (rs_W[lo:hi] + S @ m0[lo:hi])
+        for pos, _, V in self.groups:
+            theta[pos] = np.matmul(V, x[pos][:, :, None])[:, :, 0]
         return theta
 
     def e_theta_(self, m0, theta_vb):
         """R/elbo.R:166-180."""
-        tot = 0.0
-        for i, ((lo, hi), S) in enumerate(zip(self.slices, self.S0_inv)):
-            dlt = theta_vb[lo:hi] - m0[lo:hi]
-            tot += (self.sum_log_det[i] - dlt @ (S @ dlt) - self.trace_SV[i] + (hi - lo)) / 2
-        return float(tot)
+        dlt = theta_vb - m0
+        quad = 0.0
+        for pos, S, _ in self.groups:
+            db = dlt[pos]
+            quad += float(np.sum(db * np.matmul(S, db[:, :, None])[:, :, 0]))
+        return self.e_theta_const - quad / 2
 
 
 def inv_mills_ratio_(y, U, log_1_pnorm_U, log_pnorm_U):
@@ -164,11 +182,13 @@ def inv_mills_ratio_(y, U, log_1_pnorm_U, log_pnorm_U):
     return np.where(m > -U, -U, m)
 
 
-def row_sums_W_struct_(rs_gam, d, theta_vb):
+def row_sums_W_struct_(rs_gam, d, theta_vb, log_pnorm=None, log_1_pnorm=None):
     """rowSums(update_W_struct_(gam_vb, theta_vb)) (R/update_vb.R:389-399) from rowSums(gam_vb):
-    W_jk = gam_jk (imr1_j - imr0_j) + theta_j + imr0_j."""
-    log_pnorm = log_ndtr(theta_vb)
-    log_1_pnorm = log_ndtr(-theta_vb)
+    W_jk = gam_jk (imr1_j - imr0_j) + theta_j + imr0_j.  The two log-probabilities may be
+    handed in when the caller already has them."""
+    if log_pnorm is None:
+        log_pnorm = log_ndtr(theta_vb)
+        log_1_pnorm = log_ndtr(-theta_vb)
     imr0 = inv_mills_ratio_(0, theta_vb, log_1_pnorm, log_pnorm)
     imr1 = inv_mills_ratio_(1, theta_vb, log_1_pnorm, log_pnorm)
     return (imr1 - imr0) * rs_gam + d * (theta_vb + imr0)
