@@ -154,7 +154,7 @@ typedef struct locus_hip_sweep_args {
                                    per workgroup (1, 2; 0 = planned from d), S ignored,
                                    G = 16-row tiles per matrix wave (0 = smallest that fits n);
                                    NPL = -2: streaming kernel (any n; what "automatic" picks
-                                   above 2048 rows), C, S, G ignored */
+                                   above 4096 rows), C, S, G ignored */
 } locus_hip_sweep_args;
 
 /* One CAVI sweep over the covariates in `shuffled_ind` order; logit = 0 runs the
@@ -168,7 +168,7 @@ int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream);
 
 /* Geometry the library would pick for (n, d): fills cfg[4] = NPL, C, S, G
  * ({-1, 0, 0, 0}: the matrix-core sweep, launches planned from d; {-2, 0, 0, 0}: the
- * streaming kernel, n > 2048). */
+ * streaming kernel, n > 4096). */
 int locus_hip_sweep_config(int64_t n, int64_t d, int logit, int32_t* cfg);
 
 /* out = Y - A - Zmu                       (W2 == NULL; same formula both directions)

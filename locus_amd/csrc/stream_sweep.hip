@@ -1,5 +1,4 @@
-// CAVI sweep for n beyond the register-resident kernels (n > 2048; identity family also n > 2016
-// when the vector kernel is not chosen): one workgroup per response, the residual column in LDS
+// CAVI sweep for n beyond the register-resident kernels (n > 4096): one workgroup per response, the residual column in LDS
 // when it fits (else updated in place in global memory), X columns read through L2, which all the
 // workgroups share because they advance through the same sweep order.
 //

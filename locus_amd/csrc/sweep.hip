@@ -19,6 +19,9 @@ LOCUS_DECL(8, 1)
 LOCUS_DECL(16, 0)
 LOCUS_DECL(16, 1)
 #undef LOCUS_DECL
+// "wide" NPL = 16 instantiations: 4 staging pieces per thread, 2048 < n <= 4096
+int launch_sweep_wide_npl16_l0(const SweepParams&, int, dim3, dim3, size_t, hipStream_t);
+int launch_sweep_wide_npl16_l1(const SweepParams&, int, dim3, dim3, size_t, hipStream_t);
 
 static const int kCs[] = {1, 2, 4, 5, 8, 10, 16};
 
@@ -33,10 +36,11 @@ static int max_c(int npl, bool logit)
     return 2;
 }
 
-static int vgpr_estimate(int npl, int c, bool logit)
+static int vgpr_estimate(int npl, int c, bool logit, bool wide = false)
 {
     // keep in step with sweep_depth() / sweep_max_threads() of sweep_kernel.h
     const int regs = 2 * npl * c * (logit ? 2 : 1);
+    if (wide) return regs + 16 * (regs <= 64 ? 4 : 2) + 90;
     const int depth = regs <= 64 ? 6 : (regs <= 112 ? 4 : 2);
     return regs + 8 * depth + 90;
 }
@@ -104,9 +108,13 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
             if (npl * s >= 2 * units && npl * s > 2) continue;  // more than 2x row padding
             for (int c : kCs) {
                 if (c > max_c(npl, logit)) continue;
-                const int vg = vgpr_estimate(npl, c, logit);
+                // n > 2048: only the wide NPL = 16 instantiations (4 staging pieces per thread)
+                const bool wide = units > 32;
+                if (wide && (npl != 16 || c > (logit ? 1 : 4))) continue;
+                const int vg = vgpr_estimate(npl, c, logit, wide);
                 const int max_thr = vg <= 128 ? 1024 : 512;
-                const int gmin = std::max(1, (npl + 3) / 4);  // <= 2 staging pieces per thread
+                const int gmin = wide ? std::max(1, 8 / s)                     // 512 threads
+                                      : std::max(1, (npl + 3) / 4);  // <= 2 staging pieces per thread
                 for (int g : {1, 2, 4, 8, 16}) {
                     if (g < gmin) continue;
                     const int thr = 64 * s * g;
@@ -138,7 +146,7 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
             }
         }
     }
-    if (bc.NPL == 0) bc = SweepConfig{-2, 0, 0, 0};  // n > 2048: the streaming kernel
+    if (bc.NPL == 0) bc = SweepConfig{-2, 0, 0, 0};  // n > 4096: the streaming kernel
     *out = bc;
     return 0;
 }
@@ -154,13 +162,18 @@ int launch_sweep(const SweepParams& prm_in, const SweepConfig& cfg, bool logit, 
         return LOCUS_HIP_EINVAL;
     }
     const int thr = 64 * cfg.S * cfg.G;
-    if ((prm.ld / 2 + thr - 1) / thr > 2) {
-        set_error("sweep: workgroup too small to stage an X column (G >= NPL/4)");
+    const int pieces = (prm.ld / 2 + thr - 1) / thr;  // 16-byte pieces of a column per thread
+    const bool wide = pieces > 2;
+    if (pieces > 4 || (wide && cfg.NPL != 16)) {
+        set_error("sweep: workgroup too small to stage an X column (G >= NPL/4; NPL = 16: G >= NPL/8)");
         return LOCUS_HIP_EINVAL;
     }
     const long n_wg = ((long)prm.d + (long)cfg.G * cfg.C - 1) / ((long)cfg.G * cfg.C);
     dim3 grid((unsigned)n_wg), block((unsigned)thr);
     const size_t lds = sweep_lds_bytes(cfg);
+    if (wide)
+        return logit ? launch_sweep_wide_npl16_l1(prm, cfg.C, grid, block, lds, stream)
+                     : launch_sweep_wide_npl16_l0(prm, cfg.C, grid, block, lds, stream);
 #define LOCUS_CASE(npl)                                                                        \
     case npl:                                                                                  \
         return logit ? launch_sweep_npl##npl##_l1(prm, cfg.C, grid, block, lds, stream)       \

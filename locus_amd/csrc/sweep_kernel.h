@@ -117,7 +117,8 @@ __device__ __forceinline__ double reduce_merge(const double (&v)[C], int sub)
     return U;
 }
 
-constexpr int kMaxPieces = 2;  // 16-byte X pieces a thread stages per column (G >= NPL/4)
+constexpr int kMaxPieces = 2;  // 16-byte X pieces a thread stages per column (G >= NPL/4);
+                               // the "wide" instantiations (PCS = 4) cover 2048 < n <= 4096
 constexpr int kStepPad = 12;   // nsteps is padded to a multiple of every prefetch depth
 constexpr int kStepTail = 16;  // readable step records past nsteps_pad
 
@@ -126,21 +127,22 @@ constexpr int kStepTail = 16;  // readable step records past nsteps_pad
 // vmcnt retires in order: a wait for a young load would also wait for every older one, so a
 // short-distance load behind a long-distance HBM miss would serialise the sweep on HBM
 // latency.  Small geometries (latency regime) have the registers for a deep ring.
-template <int NPL, int C, bool LOGIT>
+template <int NPL, int C, bool LOGIT, int PCS = kMaxPieces>
 constexpr int sweep_depth()
 {
     constexpr int regs = 2 * NPL * C * (LOGIT ? 2 : 1);
+    if (PCS > kMaxPieces) return regs <= 64 ? 4 : 2;  // 4 PCS registers per ring slot
     return regs <= 64 ? 6 : (regs <= 112 ? 4 : 2);
 }
 
 // Every instantiation is built for <= 256 VGPRs (two waves per SIMD): arithmetic
 // VGPRs stop at 256 on gfx950, anything above lives in AGPRs behind
 // v_accvgpr moves, which costs more than it buys for an FMA-bound loop.
-template <int NPL, int C, bool LOGIT>
+template <int NPL, int C, bool LOGIT, int PCS = kMaxPieces>
 constexpr int sweep_max_threads()
 {
     constexpr int est = 2 * NPL * C * (LOGIT ? 2 : 1) +
-                        4 * kMaxPieces * sweep_depth<NPL, C, LOGIT>() + 90;
+                        4 * PCS * sweep_depth<NPL, C, LOGIT, PCS>() + 90;
     return est <= 128 ? 1024 : 512;
 }
 
@@ -167,8 +169,8 @@ __device__ unsigned long long g_sweep_stamps[kStampSlots * 4096];
 #define LOCUS_STAMP(k) do { } while (0)
 #endif
 
-template <int NPL, int C, bool LOGIT>
-__global__ void __launch_bounds__((sweep_max_threads<NPL, C, LOGIT>()))
+template <int NPL, int C, bool LOGIT, int PCS = kMaxPieces>
+__global__ void __launch_bounds__((sweep_max_threads<NPL, C, LOGIT, PCS>()))
 sweep_kernel(const SweepParams P)
 {
     static_assert(NPL % 2 == 0 && NPL >= 2, "NPL must be even");
@@ -272,7 +274,7 @@ sweep_kernel(const SweepParams P)
     const size_t pd = (size_t)P.p * d;
     const int kls = cvalid ? kl : 0;  // safe column for speculative state loads
 
-    constexpr int D = sweep_depth<NPL, C, LOGIT>();
+    constexpr int D = sweep_depth<NPL, C, LOGIT, PCS>();
     const StepPtr steps = (StepPtr)(unsigned long long)P.steps;
 
     // ---- X staging: zero the ring once, stage columns of steps 0 and 1 -------
@@ -286,7 +288,7 @@ sweep_kernel(const SweepParams P)
         for (int e = tid; e < npieces; e += nthr) dst[e] = src[e];
     }
     // ---- prefetch rings: X pieces of steps 2..D+1, per-response state of steps 0..D-1 ----
-    double2 xq[D][kMaxPieces];
+    double2 xq[D][PCS];
     double bo_ring[D];
     double s2_ring[LOGIT ? D : 1];
     double xw_ring[LOGIT ? D : 1];
@@ -302,7 +304,7 @@ sweep_kernel(const SweepParams P)
         const double2* src =
             reinterpret_cast<const double2*>(P.Xp + (size_t)steps[u + 2].j * P.ld);
 #pragma unroll
-        for (int q = 0; q < kMaxPieces; ++q) {
+        for (int q = 0; q < PCS; ++q) {
             const int e = tid + q * nthr;
             xq[(u + 2) % D][q] = (e < npieces) ? src[e] : make_double2(0.0, 0.0);
         }
@@ -462,7 +464,7 @@ sweep_kernel(const SweepParams P)
                 const double2* src =
                     reinterpret_cast<const double2*>(P.Xp + (size_t)st_jx * P.ld);
 #pragma unroll
-                for (int q = 0; q < kMaxPieces; ++q) {
+                for (int q = 0; q < PCS; ++q) {
                     const int e = tid + q * nthr;
                     if (e < npieces) dst[e] = xq[(u + 2) % D][q];
                     xq[(u + 2) % D][q] = (e < npieces) ? src[e] : make_double2(0.0, 0.0);

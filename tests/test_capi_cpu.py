@@ -53,14 +53,17 @@ def test_geometry_chooser(n, d, logit, monkeypatch):
     assert g >= (npl + 3) // 4                        # <= 2 staging pieces per thread
 
 
-@pytest.mark.parametrize("n,logit", [(2049, 0), (2049, 1), (100000, 0)])
-def test_geometry_chooser_beyond_the_register_kernels(n, logit, monkeypatch):
-    """n > 2048 (vector kernel) / 2016 (matrix-core kernel): the streaming kernel, NPL = -2."""
+@pytest.mark.parametrize("n,logit", [(2049, 0), (2049, 1), (4096, 1), (4097, 0), (100000, 0)])
+def test_geometry_chooser_beyond_2048_rows(n, logit):
+    """2048 < n <= 4096: the wide vector instantiations (NPL = 16, S = 4, G = 2: 512 threads,
+    four staging pieces each); above: the streaming kernel, NPL = -2."""
     from locus_amd import _lib
-    monkeypatch.setenv("LOCUS_HIP_SWEEP_VECTOR", "1")
     cfg = (ctypes.c_int32 * 4)()
     _lib.check(_lib.lib().locus_hip_sweep_config(n, 10, logit, cfg))
-    assert list(cfg) == [-2, 0, 0, 0]
+    if n <= 4096:
+        assert list(cfg)[0] == 16 and list(cfg)[2:] == [4, 2] and cfg[1] <= (1 if logit else 4)
+    else:
+        assert list(cfg) == [-2, 0, 0, 0]
 
 
 def test_rejects_bad_arguments_before_touching_the_gpu():

@@ -137,17 +137,30 @@ def test_streaming_kernel_forced(oracle, hip, variant, shape, monkeypatch):
 
 
 @pytest.mark.parametrize("variant,n", [("identity", 2049), ("struct", 3000), ("z", 2500),
-                                       ("probit", 4100), ("logit", 2100), ("logit", 8000),
-                                       ("identity", 16001)])
+                                       ("probit", 4096), ("logit", 2100), ("logit", 4090),
+                                       ("probit", 4100), ("logit", 8000), ("identity", 16001)])
 def test_more_than_2048_samples(oracle, hip, variant, n, monkeypatch):
-    """No limit on n: above 2048 rows (2016 for the matrix-core kernel) the library picks the
-    streaming kernel by itself -- residual column in LDS up to 120 KB (n <= 15 359; logit, which
-    also keeps the 2 psi column: n <= 7679), in global memory beyond."""
+    """No limit on n.  2048 < n <= 4096: the wide instantiations of the vector kernel (NPL = 16,
+    four row slices, four staging pieces per thread).  Above: the streaming kernel -- residual
+    column in LDS up to 120 KB (n <= 15 359; logit, which also keeps the 2 psi column:
+    n <= 7679), in global memory beyond."""
     monkeypatch.delenv("LOCUS_HIP_SWEEP_CFG", raising=False)
-    inp = inputs_for(variant, n, 24, 5, seed=n)
+    inp = inputs_for(variant, n, 24, 2 * (n % 7) + 3, seed=n)
     ref = call_variant(oracle, variant, inp)
     got = call_variant(hip, variant, inp)
     assert_parity(got, ref, what=f"{variant} n={n}")
+
+
+@pytest.mark.parametrize("geom", ["16,1,4,2", "16,2,4,2", "16,4,4,2"])
+def test_wide_vector_geometries(oracle, hip, geom, monkeypatch):
+    """The wide (2048 < n <= 4096) instantiations, every C, ragged rows and responses."""
+    npl, c, s, g = map(int, geom.split(","))
+    inp = inputs_for("identity", 4096 - 37, 21, 2 * c * g + 3, seed=c)
+    ref = call_variant(oracle, "identity", inp)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", geom)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_VECTOR", "1")
+    got = call_variant(hip, "identity", inp)
+    assert_parity(got, ref, what=f"identity wide geom {geom}")
 
 
 @pytest.mark.parametrize("vector", [False, True, "stream"])
