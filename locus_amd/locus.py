@@ -84,8 +84,12 @@ def locus(Y, X, p0_av, Z=None, link="identity", ind_bin=None, list_hyper=None, l
     if list_init is None:
         # the p x d initial matrices are drawn by each rank on its GPU (prepare.DrawnMatrix);
         # the block-wise path slices them by rows on the host, so it keeps the host draw
-        draw = auto_set_init_ if vec_fac_bl is not None else auto_set_init_drawn_
-        list_init = draw(Y, p, p_star, q=q, user_seed=user_seed, link=link, ind_bin=ind_bin)
+        kw_i = dict(q=q, user_seed=user_seed, link=link, ind_bin=ind_bin)
+        if vec_fac_bl is not None:
+            list_init = auto_set_init_(Y, p, p_star, **kw_i)
+        else:
+            list_init = auto_set_init_drawn_(Y, p, p_star, **kw_i,
+                                             device_type="cpu" if _test_backend else "cuda")
     else:
         list_init = dict(list_init)
     if link != "identity":

@@ -199,13 +199,17 @@ class DrawnMatrix:
                    (gam_vb, R/set_hyper_init.R:765);
           "normal" N(0, 1) (mu_beta_vb, :780);
           "inv_gamma2" 1 / Gamma(shape 2, scale param) (logit sig2_beta_vb, :811).
-    np.asarray(m) materialises the matrix (column-major) for host-side callers."""
+    np.asarray(m) materialises the matrix (column-major) for host-side callers.
+    torch's CPU and GPU generators give different streams, so a matrix belongs to ONE device
+    type: `device_type` ("cuda" / "cpu"), or, if None, the type of the first draw; asking for
+    columns on the other type raises instead of silently returning different numbers."""
     CHUNK = 256
     KINDS = ("beta1", "normal", "inv_gamma2")
 
-    def __init__(self, kind, p, d, seed=None, param=None):
+    def __init__(self, kind, p, d, seed=None, param=None, device_type=None):
         assert kind in self.KINDS
         self.kind, self.shape, self.param = kind, (int(p), int(d)), param
+        self.device_type = device_type
         ss = seed if isinstance(seed, np.random.SeedSequence) else np.random.SeedSequence(seed)
         self.seed = int(ss.generate_state(1, dtype=np.uint64)[0])
         self.ndim, self.dtype = 2, np.dtype(np.float64)
@@ -230,6 +234,12 @@ class DrawnMatrix:
     def columns_on(self, cols, device):
         """[p][len(cols)] row-major float64 tensor on `device`; cols: slice or index array."""
         import torch
+        device = torch.device(device)
+        if self.device_type is None:
+            self.device_type = device.type
+        elif device.type != self.device_type:
+            raise ValueError(f"this DrawnMatrix is drawn on '{self.device_type}' devices, "
+                             f"not on '{device.type}'")
         p, d = self.shape
         cols = np.arange(d)[cols]
         out = torch.empty((p, len(cols)), dtype=torch.float64, device=device)
@@ -247,12 +257,14 @@ class DrawnMatrix:
 
     def __array__(self, dtype=None, copy=None):
         import torch
-        dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        kind = self.device_type or ("cuda" if torch.cuda.is_available() else "cpu")
+        dev = torch.device(kind)
         from .hostio import to_host_F
         return to_host_F(self.columns_on(slice(None), dev))
 
 
-def auto_set_init_drawn_(Y, p, p_star, q=None, user_seed=None, link="identity", ind_bin=None):
+def auto_set_init_drawn_(Y, p, p_star, q=None, user_seed=None, link="identity", ind_bin=None,
+                         device_type=None):
     """auto_set_init_ with the p x d matrices (gam_vb, mu_beta_vb, logit sig2_beta_vb) left as
     DrawnMatrix recipes for the drivers to draw on their GPUs; everything else as auto_set_init_."""
     d = Y.shape[1]
@@ -262,10 +274,11 @@ def auto_set_init_drawn_(Y, p, p_star, q=None, user_seed=None, link="identity", 
     ss = np.random.SeedSequence(user_seed).spawn(3)
     shape2 = d * (p - np.asarray(p_star, dtype=np.float64)) / p_star
     init["p_init"] = p
-    init["gam_vb"] = DrawnMatrix("beta1", p, d, ss[0], shape2)
-    init["mu_beta_vb"] = DrawnMatrix("normal", p, d, ss[1])
+    init["gam_vb"] = DrawnMatrix("beta1", p, d, ss[0], shape2, device_type)
+    init["mu_beta_vb"] = DrawnMatrix("normal", p, d, ss[1], device_type=device_type)
     if link == "logit":
-        init["sig2_beta_vb"] = DrawnMatrix("inv_gamma2", p, d, ss[2], init["sig2_inv_vb"])
+        init["sig2_beta_vb"] = DrawnMatrix("inv_gamma2", p, d, ss[2], init["sig2_inv_vb"],
+                                           device_type)
     return init
 
 

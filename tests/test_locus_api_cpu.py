@@ -163,25 +163,27 @@ def test_drawn_initial_values():
     import torch
     from locus_amd.prepare import DrawnMatrix, auto_set_init_drawn_
     cpu = torch.device("cpu")
-    m = DrawnMatrix("beta1", 400, 600, 5, 50.0)
+    m = DrawnMatrix("beta1", 400, 600, 5, 50.0, "cpu")
     full = np.asarray(m)
     assert full.shape == (400, 600) and full.flags.f_contiguous
     assert abs(full.mean() - 1 / 51) < 2e-4 and full.min() >= 0 and full.max() < 1
     np.testing.assert_array_equal(m.columns_on(slice(100, 333), cpu).numpy(), full[:, 100:333])
     idx = np.array([5, 599, 256, 3, 511])
     np.testing.assert_array_equal(m.columns_on(idx, cpu).numpy(), full[:, idx])
-    np.testing.assert_array_equal(np.asarray(DrawnMatrix("beta1", 400, 600, 5, 50.0)), full)
-    assert not np.array_equal(np.asarray(DrawnMatrix("beta1", 400, 600, 6, 50.0)), full)
-    rows = np.asarray(DrawnMatrix("beta1", 3, 4000, 1, np.array([1.0, 9.0, 99.0])))
+    np.testing.assert_array_equal(np.asarray(DrawnMatrix("beta1", 400, 600, 5, 50.0, "cpu")), full)
+    assert not np.array_equal(np.asarray(DrawnMatrix("beta1", 400, 600, 6, 50.0, "cpu")), full)
+    rows = np.asarray(DrawnMatrix("beta1", 3, 4000, 1, np.array([1.0, 9.0, 99.0]), "cpu"))
     np.testing.assert_allclose(rows.mean(axis=1), [0.5, 0.1, 0.01], rtol=0.08)
-    z = np.asarray(DrawnMatrix("normal", 300, 400, 2))
+    z = np.asarray(DrawnMatrix("normal", 300, 400, 2, device_type="cpu"))
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
-    g = np.asarray(DrawnMatrix("inv_gamma2", 300, 400, 2, 1e-2))
+    g = np.asarray(DrawnMatrix("inv_gamma2", 300, 400, 2, 1e-2, "cpu"))
     assert abs(np.median(1 / g) / (1e-2 * 1.67835) - 1) < 0.02      # median of Gamma(2, scale)
     Y = np.random.default_rng(0).normal(size=(50, 7))
     ini = auto_set_init_drawn_(Y, 30, 3, q=2, user_seed=4, link="logit")
     assert all(isinstance(ini[k], DrawnMatrix) for k in ("gam_vb", "mu_beta_vb", "sig2_beta_vb"))
     assert ini["alpha_vb"].shape == (2, 7) and ini["sig2_alpha_vb"].shape == (2, 7)
+    with pytest.raises(ValueError):                                 # one device type per matrix
+        DrawnMatrix("normal", 4, 4, 1, device_type="cuda").columns_on(slice(None), cpu)
     ini = auto_set_init_drawn_(Y, 30, 3, user_seed=4)
     assert ini["sig2_beta_vb"].shape == (7,) and ini["tau_vb"].shape == (7,)
 
