@@ -49,9 +49,10 @@ def parse():
     ap.add_argument("--d", type=int, default=10000)
     ap.add_argument("--p0", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--to-tol", type=float, default=0.0,
-                    help="after the timed steps keep iterating until |dELBO| < TOL (R/locus.R:243 uses "
-                         "0.1) and report the secondary metric 'time to ELBO tol' (0 = skip)")
+    ap.add_argument("--to-tol", type=float, default=0.1,
+                    help="after the timed steps keep iterating until |dELBO| < TOL (default 0.1 = "
+                         "R/locus.R:243) and report the secondary metric 'time to ELBO tol' "
+                         "(0 = skip)")
     ap.add_argument("--cpu-covariates", type=int, default=0,
                     help="covariates of the CPU sample (0 = sized for ~15 s)")
     return ap.parse_args()

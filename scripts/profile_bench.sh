@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf $OUT
 mkdir -p $OUT
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --to-tol 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
