@@ -36,4 +36,14 @@ r = ref_driver.locus_core_(sim["Y"], sim["X"], hy, ini["gam_vb"], ini["mu_beta_v
 np.savez_compressed(os.path.join(HERE, "driver_identity_c1.npz"),
                     elbo_trace=np.array([x[1] for x in tr]), it=r["it"],
                     selected=np.argwhere(r["gam_vb"] > 0.5))
+
+# the restated drivers (oracle/ref_driver.py) on the small problems of tests/test_drivers_cpu.py:
+# every link / variant, 3 iterations
+import test_drivers_cpu as T  # noqa: E402
+blob = {}
+for kind in T.KINDS:
+    res = T._run(kind, "ref")
+    for k in T.GOLDEN_KEYS:
+        blob[f"{kind.replace('-', '_')}__{k}"] = np.asarray(res[k])
+np.savez_compressed(os.path.join(HERE, "drivers_small.npz"), **blob)
 print("golden fixtures written")

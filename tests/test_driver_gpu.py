@@ -364,3 +364,48 @@ def test_cross_validation_on_gpu(oracle, hip, with_z):
     cv = set_cv(n, p, n_folds=2, size_p0_av_grid=2, tol_cv=1.0, maxit_cv=5, verbose=False)
     vb = locus(sim["Y"], sim["X"], None, Z=Z, list_cv=cv, user_seed=5, maxit=3, verbose=False)
     assert vb["p_star"] in cv["p0_av_grid"] and vb["cv_lb_mat"].shape == (2, len(cv["p0_av_grid"]))
+
+
+# ---- committed fixtures (tests/golden/, written by tests/golden/make_golden.py) ----------------
+@pytest.mark.parametrize("variant", ["identity", "z", "struct", "probit", "logit", "batch",
+                                     "zbatch", "probitbatch"])
+def test_hip_routines_against_golden_vectors(hip, variant):
+    """The eight C-ABI routines on the committed input / output vectors."""
+    import os
+    from helpers import ATOL, INOUT, RTOL, call_variant
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", f"sweep_{variant}.npz"))
+    inp = {k[3:]: (np.asfortranarray(f[k]) if f[k].ndim == 2 else
+                   (f[k] if f[k].ndim == 1 else float(f[k])))
+           for k in f.files if k.startswith("in_")}
+    out = call_variant(hip, variant, inp)
+    for k in INOUT:
+        np.testing.assert_allclose(out[k], f["out_" + k], rtol=RTOL, atol=ATOL, err_msg=k)
+
+
+def test_hip_drivers_against_golden_results(hip):
+    """Every driver (identity, annealed, struct, logit, probit, z, annealed z, mix) on the GPU
+    against the committed results of the restated R drivers."""
+    import test_drivers_cpu as T
+    for kind in T.KINDS:
+        T.check_against_golden(kind, T._run(kind, "hip"), rtol=1e-9)
+
+
+def test_identity_c1_elbo_trace_against_golden(hip):
+    """BASELINE config C1 to convergence at tol = 0.1: the committed ELBO trace, iteration count
+    and selected (covariate, response) pairs of the restated driver."""
+    import os
+    from locus_amd.locus_core import locus_core_
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_
+    from locus_amd.simulate import simulate
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "driver_identity_c1.npz"))
+    sim = simulate(200, 500, 20, 15, seed=123)
+    hy = auto_set_hyper_(sim["Y"], 500, 15)
+    ini = auto_set_init_(sim["Y"], 500, 15, user_seed=123)
+    rng = np.random.default_rng(1)
+    tr = []
+    r = locus_core_(sim["Y"], sim["X"], hy, ini["gam_vb"], ini["mu_beta_vb"], ini["sig2_beta_vb"],
+                    ini["tau_vb"], tol=0.1, maxit=100,
+                    perm_fn=lambda it: rng.permutation(500).astype(np.float64), trace=tr)
+    assert r["it"] == int(f["it"]) and r["converged"]
+    np.testing.assert_allclose([x[1] for x in tr], f["elbo_trace"], rtol=1e-8)
+    np.testing.assert_array_equal(np.argwhere(r["gam_vb"] > 0.5), f["selected"])

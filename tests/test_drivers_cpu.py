@@ -99,8 +99,10 @@ def _mix_problem(n=N, p=P, d=D, p0=P0, seed=17):
 
 
 def _run(kind, which, comm=None):
-    """which = 'ref' (oracle/ref_driver.py, full matrices) or 'got' (product host side on the
-    CPU emulation of the device layer)."""
+    """which = 'ref' (oracle/ref_driver.py, full matrices), 'got' (product host side on the
+    CPU emulation of the device layer) or 'hip' (the product on the GPU, tests/test_driver_gpu.py)."""
+    import cpu_device
+    backend = None if which == "hip" else cpu_device
     sim, hyper, init, extra, perm_fn, aperm_fn = _problem(kind)
     Y, X = sim["Y"], sim["X"]
     common = dict(tol=1e-30, maxit=MAXIT, perm_fn=perm_fn)
@@ -110,10 +112,9 @@ def _run(kind, which, comm=None):
         if which == "ref":
             from oracle import ref_driver as R
             return R.locus_mix_core_(*args, alpha_perm_fn=aperm_fn, **common)
-        import cpu_device
         from locus_amd.locus_mix_core import locus_mix_core_
         return locus_mix_core_(*args, alpha_perm_fn=aperm_fn, comm=comm, full_output=True,
-                               _test_backend=cpu_device, **common)
+                               _test_backend=backend, **common)
     if kind in ("z", "z-anneal"):
         an = (1, 2.0, 2) if kind == "z-anneal" else None
         args = (Y, X, extra["Z"], hyper, init["gam_vb"], init["alpha_vb"], init["mu_beta_vb"],
@@ -121,10 +122,9 @@ def _run(kind, which, comm=None):
         if which == "ref":
             from oracle import ref_driver as R
             return R.locus_z_core_(*args, anneal=an, alpha_perm_fn=aperm_fn, **common)
-        import cpu_device
         from locus_amd.locus_z_core import locus_z_core_
         return locus_z_core_(*args, anneal=an, alpha_perm_fn=aperm_fn, comm=comm,
-                             full_output=True, _test_backend=cpu_device, **common)
+                             full_output=True, _test_backend=backend, **common)
     if which == "ref":
         from oracle import ref_driver as R
         if kind in ("identity", "anneal"):
@@ -138,8 +138,7 @@ def _run(kind, which, comm=None):
         fn = getattr(R, f"locus_{kind}_core_")
         return fn(Y, X, extra["Z"], hyper, init["gam_vb"], init["alpha_vb"], init["mu_beta_vb"],
                   init["sig2_alpha_vb"], init["sig2_beta_vb"], alpha_perm_fn=aperm_fn, **common)
-    import cpu_device
-    kw = dict(common, comm=comm, full_output=True, _test_backend=cpu_device)
+    kw = dict(common, comm=comm, full_output=True, _test_backend=backend)
     if kind in ("identity", "anneal"):
         from locus_amd.locus_core import locus_core_
         return locus_core_(Y, X, hyper, init["gam_vb"], init["mu_beta_vb"], init["sig2_beta_vb"],
@@ -171,6 +170,27 @@ def _compare(kind, got, ref):
 @pytest.mark.parametrize("kind", KINDS)
 def test_host_side_single_rank(oracle, kind):
     _compare(kind, _run(kind, "got"), _run(kind, "ref"))
+
+
+GOLDEN_KEYS = ("gam_vb", "mu_beta_vb", "beta_vb", "lb_opt")
+
+
+def check_against_golden(kind, res, rtol):
+    """Committed results of the restated drivers (tests/golden/drivers_small.npz, written by
+    tests/golden/make_golden.py) for the problems of _problem()."""
+    f = np.load(os.path.join(HERE, "golden", "drivers_small.npz"))
+    key = kind.replace("-", "_")
+    for k in GOLDEN_KEYS[:3]:
+        np.testing.assert_allclose(res[k], f[f"{key}__{k}"], rtol=rtol, atol=1e-12,
+                                   err_msg=f"{kind} {k}")
+    assert abs(res["lb_opt"] - float(f[f"{key}__lb_opt"])) <= max(rtol, 1e-8) * abs(res["lb_opt"])
+    assert np.array_equal(res["gam_vb"] > 0.5, f[f"{key}__gam_vb"] > 0.5)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_restated_drivers_against_golden(oracle, kind):
+    """Guards oracle/ref_driver.py against drift."""
+    check_against_golden(kind, _run(kind, "ref"), rtol=1e-11)
 
 
 def _free_port():
