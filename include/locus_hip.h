@@ -267,6 +267,54 @@ int locus_hip_bin_rows_dev(const double* state, const double* s2jk, double s2c, 
                            double* ent, double* gls, double* m2, int64_t p, int64_t d, double eps,
                            void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* 3. Resident context (host pointers; state kept on the GPU between calls)    */
+/* ------------------------------------------------------------------------- */
+/* For a host that cannot hold device memory itself -- the R session of the reference.  The loop
+ * body of locus_core_ / locus_z_core_ / locus_struct_core_ (R/locus_core.R:57-211) becomes
+ *     ctx_create(X, Y)                               once   (X, Y as passed to coreLoop)
+ *     ctx_set_state(gam_vb, mu_beta_vb, mat_z_mu)    once   (R/locus_core.R:36-42)
+ *     per iteration: the R updates of the length-p / length-d quantities, then
+ *       ctx_sweep(...)  = coreLoop (R/locus_core.R:90-95) + rowSums(gam_vb) + the column sums
+ *                         update_eta/kappa/lambda/nu_vb_ and elbo_ need (R/update_vb.R:198-237)
+ *     ctx_get_state(...)                              once, at the end
+ * so that X, Y and the three p x d matrices stay in HBM and 3 p + 4 d doubles go up, p + 4 d + 1
+ * come back per iteration.  All calls are synchronous; a context belongs to the device that was
+ * current at creation and is not thread-safe. */
+typedef struct locus_hip_ctx locus_hip_ctx;
+
+/* X n x p, Y n x d column-major, as given to coreLoop (src/coreLoop.cpp:19-20). */
+int locus_hip_ctx_create(const double* X, const double* Y, int64_t n, int64_t p, int64_t d,
+                         locus_hip_ctx** ctx);
+
+/* gam_vb, mu_beta_vb p x d column-major; forms beta_vb = gam_vb * mu_beta_vb and
+ * mat_x_m1 = X beta_vb (R/locus_core.R:36-40).  mat_z_mu (n x d) or NULL: the term coreZLoop /
+ * coreProbitLoop subtract (src/coreLoop.cpp:80); pass it again whenever alpha_vb changed. */
+int locus_hip_ctx_set_state(locus_hip_ctx* ctx, const double* gam_vb, const double* mu_beta_vb,
+                            const double* mat_z_mu);
+
+/* One sweep with the arguments of coreLoop (probit: tau_vb = 1, log_tau_vb = 0, sig2_beta_vb
+ * repeated; struct: log Phi / log(1 - Phi) in place of log_om / log_1_min_om, c = 1).  Outputs,
+ * each may be NULL: rs_gam[p] = rowSums(gam_vb); col_stats[4][d] = colSums(gam_vb),
+ * colSums(m2_beta), colSums(beta_vb^2), colSums((Y - mat_x_m1 - mat_z_mu)^2); *ent_sum =
+ * sum gam log(gam + eps) + (1 - gam) log(1 - gam + eps) (R/elbo.R:46-52). */
+int locus_hip_ctx_sweep(locus_hip_ctx* ctx, const double* log_om_vb,
+                        const double* log_1_min_om_vb, double log_sig2_inv_vb,
+                        const double* log_tau_vb, const double* sig2_beta_vb,
+                        const double* tau_vb, const double* shuffled_ind, double c, double ent_eps,
+                        double* rs_gam, double* col_stats, double* ent_sum);
+
+/* The same three outputs for the CURRENT state (before the first sweep: the sums
+ * R/locus_core.R:36-42 forms from the initial values; sig2_beta_vb[d] enters m2_beta). */
+int locus_hip_ctx_stats(locus_hip_ctx* ctx, const double* sig2_beta_vb, double ent_eps,
+                        double* rs_gam, double* col_stats, double* ent_sum);
+
+/* The four matrices coreLoop mutates, in R's layout; each pointer may be NULL. */
+int locus_hip_ctx_get_state(locus_hip_ctx* ctx, double* gam_vb, double* mu_beta_vb,
+                            double* beta_vb, double* mat_x_m1);
+
+int locus_hip_ctx_destroy(locus_hip_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

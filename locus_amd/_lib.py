@@ -82,6 +82,14 @@ SIGNATURES = {
     "locus_hip_probit_w_dev": (_int, [_ptr] * 7 + [_i64, _i64, _ptr]),
     "locus_hip_bin_rows_dev": (_int, [_ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _dbl,
                                       _ptr]),
+    # resident context (host pointers)
+    "locus_hip_ctx_create": (_int, [_ptr, _ptr, _i64, _i64, _i64, ctypes.POINTER(_ptr)]),
+    "locus_hip_ctx_set_state": (_int, [_ptr, _ptr, _ptr, _ptr]),
+    "locus_hip_ctx_sweep": (_int, [_ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr, _dbl, _dbl,
+                                   _ptr, _ptr, ctypes.POINTER(_dbl)]),
+    "locus_hip_ctx_stats": (_int, [_ptr, _ptr, _dbl, _ptr, _ptr, ctypes.POINTER(_dbl)]),
+    "locus_hip_ctx_get_state": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr]),
+    "locus_hip_ctx_destroy": (_int, [_ptr]),
 }
 
 _lib = None

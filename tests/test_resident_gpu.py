@@ -1,0 +1,87 @@
+"""The resident-context part of the C ABI (include/locus_hip.h, section 3): host pointers in and
+out, state kept on the GPU between calls -- against the oracle routines and the restated driver."""
+import numpy as np
+import pytest
+
+from helpers import ATOL, RTOL, assert_parity, call_variant, inputs_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats_ref(out, inp, zmu=None):
+    gam, mu, beta = out["gam_vb"], out["mu_beta_vb"], out["beta_vb"]
+    R = inp["Y"] - out["mat_x_m1"] - (0.0 if zmu is None else zmu)
+    s2 = np.broadcast_to(inp["sig2_beta_vb"], (gam.shape[1],))
+    return gam.sum(axis=1), np.stack([gam.sum(axis=0), (gam * (mu ** 2 + s2)).sum(axis=0),
+                                      (beta ** 2).sum(axis=0), (R ** 2).sum(axis=0)])
+
+
+@pytest.mark.parametrize("variant,shape", [("identity", (200, 90, 21)), ("z", (150, 40, 7)),
+                                           ("struct", (64, 33, 1)), ("identity", (2300, 24, 5))])
+def test_ctx_sweep_matches_oracle_routine(oracle, hip, variant, shape):
+    from locus_amd.resident import ResidentContext
+    n, p, d = shape
+    inp = inputs_for(variant, n, p, d, seed=n + d, c=0.7 if variant == "identity" else 1.0)
+    ref = call_variant(oracle, variant, inp)
+    zmu = inp.get("mat_z_mu") if variant == "z" else None
+    eps = np.finfo(np.float64).eps
+    with ResidentContext(inp["X"], inp["Y"]) as ctx:
+        ctx.set_state(inp["gam_vb"], inp["mu_beta_vb"], zmu)
+        st0 = ctx.get_state()
+        np.testing.assert_allclose(st0["mat_x_m1"], inp["mat_x_m1"], rtol=1e-10, atol=1e-11)
+        rs0, cs0, e0 = ctx.stats(inp["sig2_beta_vb"], eps)
+        rs_r, cs_r = _stats_ref(dict(inp), inp, zmu)
+        np.testing.assert_allclose(rs0, rs_r, rtol=1e-12)
+        np.testing.assert_allclose(cs0, cs_r, rtol=1e-10)
+        rs, cs, ent = ctx.sweep(inp["log_om_vb"], inp["log_1_min_om_vb"], inp["log_sig2_inv_vb"],
+                                inp["log_tau_vb"], inp["sig2_beta_vb"], inp["tau_vb"],
+                                inp["shuffled_ind"], inp.get("c", 1.0), eps)
+        got = ctx.get_state()
+    assert_parity(got, ref, what=f"ctx {variant} {shape}")
+    rs_r, cs_r = _stats_ref(ref, inp, zmu)
+    np.testing.assert_allclose(rs, rs_r, rtol=1e-9)
+    np.testing.assert_allclose(cs, cs_r, rtol=1e-9)
+    g = ref["gam_vb"]
+    np.testing.assert_allclose(ent, np.sum(g * np.log(g + eps) + (1 - g) * np.log(1 - g + eps)),
+                               rtol=1e-9)
+    assert e0 is not None and np.isfinite(e0)
+
+
+def test_ctx_rejects_misuse(hip):
+    from locus_amd._lib import LocusHipError
+    from locus_amd.resident import ResidentContext
+    inp = inputs_for("identity", 100, 10, 3, seed=1)
+    args = (inp["log_om_vb"], inp["log_1_min_om_vb"], inp["log_sig2_inv_vb"], inp["log_tau_vb"],
+            inp["sig2_beta_vb"], inp["tau_vb"])
+    with ResidentContext(inp["X"], inp["Y"]) as ctx:
+        with pytest.raises(LocusHipError):                       # no state yet
+            ctx.sweep(*args, inp["shuffled_ind"])
+        ctx.set_state(inp["gam_vb"], inp["mu_beta_vb"])
+        bad = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 8], dtype=np.float64)
+        with pytest.raises(LocusHipError) as ei:
+            ctx.sweep(*args, bad)
+        assert ei.value.code == -3
+        np.testing.assert_array_equal(ctx.get_state(("gam_vb",))["gam_vb"], inp["gam_vb"])
+        ctx.sweep(*args, inp["shuffled_ind"])                    # still usable afterwards
+        with pytest.raises(ValueError):
+            ctx.set_state(inp["gam_vb"][:, :2], inp["mu_beta_vb"][:, :2])
+
+
+@pytest.mark.parametrize("anneal", [None, (1, 2.0, 3)])
+def test_locus_core_through_the_resident_context(oracle, hip, anneal):
+    """R/locus_core.R's loop with ctx_sweep in place of coreLoop (the change INTEGRATION.md §2
+    describes) against the restated driver: C1, five iterations."""
+    from oracle import ref_driver
+    from locus_amd.resident import locus_core_ctx_
+    from test_driver_gpu import _setup
+    sim, hyper, init, perm_fn = _setup()
+    kw = dict(tol=1e-30, maxit=5, perm_fn=perm_fn, anneal=anneal, full_output=True)
+    args = (sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"], init["sig2_beta_vb"],
+            init["tau_vb"])
+    ref, got = ref_driver.locus_core_(*args, **kw), locus_core_ctx_(*args, **kw)
+    assert got["it"] == ref["it"] == 5
+    for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=RTOL, atol=1e-12, err_msg=k)
+    np.testing.assert_allclose(got["om_vb"], ref["om_vb"], rtol=1e-9)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+    assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
