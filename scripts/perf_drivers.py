@@ -1,5 +1,6 @@
 """Wall-clock per CAVI iteration of the drivers at BASELINE sizes (one GPU), with the ELBO trace.
-usage: python scripts/perf_drivers.py {c2|c4|c5|z} [iterations]"""
+usage: python scripts/perf_drivers.py {c2|c4|c5|z} [iterations | tol]
+       "tol": iterate to |dELBO| < 0.1 (R/locus.R:243) and report the time to convergence."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -23,7 +24,8 @@ def data(n, p, d, p0, link, seed=123):
 
 def main():
     which = sys.argv[1]
-    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    to_tol = len(sys.argv) > 2 and sys.argv[2] == "tol"
+    iters = 500 if to_tol else (int(sys.argv[2]) if len(sys.argv) > 2 else 6)
     n, p, d, link = dict(c2=(1000, 20000, 1000, "identity"), c4=(2000, 20000, 500, "logit"),
                          c5=(1000, 50000, 2000, "identity"), z=(1000, 20000, 1000, "identity"))[which]
     p0 = 100
@@ -41,7 +43,7 @@ def main():
             marks.append(time.perf_counter())
             super().append(v)
     trace = T()
-    kw = dict(tol=1e-30, maxit=iters, trace=trace)
+    kw = dict(tol=0.1 if to_tol else 1e-30, maxit=iters, trace=trace)
     t0 = time.perf_counter()
     if which == "c2":
         from locus_amd.locus_core import locus_core_
@@ -67,6 +69,9 @@ def main():
     lbs = np.array([v[1] for v in trace])
     print(f"  set-up + first iteration {1e3 * (marks[0] - t0):.0f} ms; later iterations "
           f"{np.round(per, 1).tolist()} ms; total {total:.2f} s")
+    if to_tol:
+        print(f"  to |dELBO| < 0.1: {len(lbs)} iterations, {marks[-1] - t0:.2f} s from the call "
+              f"(driver set-up included)")
     print(f"  ELBO {lbs[0]:.6e} -> {lbs[-1]:.6e}, monotone: {bool(np.all(np.diff(lbs) > -1e-6 * abs(lbs[-1])))}")
 
 
