@@ -155,6 +155,9 @@ typedef struct locus_hip_sweep_args {
                                    G = 16-row tiles per matrix wave (0 = smallest that fits n);
                                    NPL = -2: streaming kernel (any n; what "automatic" picks
                                    above 4096 rows), C, S, G ignored */
+    const double* ls2;          /* logit: [p][d] log(sig2_beta_vb) / 2 (locus_hip_half_log_dev),
+                                   the last term of src/coreLoop.cpp:125 tabulated outside the
+                                   latency-bound sweep; NULL = the kernel takes the logarithm */
 } locus_hip_sweep_args;
 
 /* One CAVI sweep over the covariates in `shuffled_ind` order; logit = 0 runs the
@@ -230,6 +233,9 @@ int locus_hip_m2_minus_b2_dev(const double* state, const double* s2jk, double s2
  * xwx = crossprod(X^2, 2 psi_vb). */
 int locus_hip_s2_from_xwx_dev(const double* xwx, double sig2_inv, double* s2, int64_t len,
                               void* stream);
+
+/* out = log(in) / 2, element-wise (locus_hip_sweep_args.ls2 from sig2_beta_vb). */
+int locus_hip_half_log_dev(const double* in, double* out, int64_t len, void* stream);
 
 /* update_chi_vb_ + update_psi_logit_vb_ (R/update_vb.R:163-174) fused with e_y_logit_
  * (R/elbo.R:210-218): c2 = Q + M^2 + Z^2 s2a + Zmu^2 + 2 M Zmu with Q = X^2 D; chi_new =

@@ -35,6 +35,7 @@ class SweepArgs(ctypes.Structure):
         ("R", _ptr), ("state", _ptr), ("stats", _ptr),
         ("workspace", _ptr), ("workspace_bytes", _i64), ("nsteps", _i64),
         ("cfg", ctypes.c_int32 * 4),
+        ("ls2", _ptr),
     ]
 
 
@@ -76,6 +77,7 @@ SIGNATURES = {
                                           _i64, _i64, _ptr]),
     "locus_hip_m2_minus_b2_dev": (_int, [_ptr, _ptr, _dbl, _ptr, _i64, _i64, _ptr]),
     "locus_hip_s2_from_xwx_dev": (_int, [_ptr, _dbl, _ptr, _i64, _ptr]),
+    "locus_hip_half_log_dev": (_int, [_ptr, _ptr, _i64, _ptr]),
     "locus_hip_logit_chi_psi_dev": (_int, [_ptr] * 11 + [_i64, _i64, _i64, _ptr]),
     "locus_hip_logit_sig2_alpha_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr]),
     "locus_hip_alpha_step_dev": (_int, [_ptr] * 7 + [_i64, _i64, _ptr]),

@@ -169,6 +169,7 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
     prm.s2 = a->s2;
     prm.xwx = a->xwx;
     prm.W2 = a->W2;
+    prm.ls2 = a->ls2;
     prm.half_lsi = a->half_lsi;
     prm.R = a->R;
     prm.state = a->state;
@@ -228,7 +229,7 @@ int run_loop(int kind, const double* X, const double* Y, double* gam, const doub
     }
 
     DevMem dX, dXp, dxtx, dY, dA, dZ, dW2, dR, dstate, dtmp, dlo, dl1, dind, dscale, dhinv, dcst,
-        ds2k, ds2, dxwx, dws;
+        ds2k, ds2, dls2, dxwx, dws;
     // X: raw copy -> packed; the raw copy is released before the big state buffers
     {
         if ((rc = upload(dX, X, np))) return rc;
@@ -264,6 +265,8 @@ int run_loop(int kind, const double* X, const double* Y, double* gam, const doub
         if ((rc = dxwx.alloc(sizeof(double) * pd))) return rc;
         LOCUS_HIP_CHECK(hipMemcpy(dtmp.p, sig2_beta, sizeof(double) * pd, hipMemcpyHostToDevice));
         if ((rc = transpose(dtmp.d(), ds2.d(), (int)d, (int)p, st))) return rc;
+        if ((rc = dls2.alloc(sizeof(double) * pd))) return rc;
+        if ((rc = half_log(ds2.d(), dls2.d(), pd, st))) return rc;
         // xwx[j][k] = sum_i X_ij^2 W2_ik : (X^2)' W2 on the matrix cores, written [p][d]
         GemmDesc g;
         g.m = (int)p; g.n = (int)d; g.k = (int)n;
@@ -290,6 +293,7 @@ int run_loop(int kind, const double* X, const double* Y, double* gam, const doub
     a.Xp = dXp.d(); a.xtx = dxtx.d(); a.shuffled_ind = dind.d(); a.lo = dlo.d(); a.l1 = dl1.d();
     a.scale = dscale.d(); a.hinv = dhinv.d(); a.cst = dcst.d(); a.s2k = ds2k.d(); a.cfac = c;
     a.s2 = ds2.d(); a.xwx = dxwx.d(); a.W2 = dW2.d(); a.half_lsi = log_sig2_inv / 2;
+    a.ls2 = dls2.d();
     a.R = dR.d(); a.state = dstate.d(); a.stats = nullptr;
     a.workspace = dws.p; a.workspace_bytes = (int64_t)workspace_bytes(n, p); a.nsteps = p;
     if ((rc = sweep_dev(&a, kind == 2, st))) return rc;
@@ -623,6 +627,12 @@ int locus_hip_s2_from_xwx_dev(const double* xwx, double sig2_inv, double* s2, in
 {
     LOCUS_REQUIRE(xwx && s2 && len >= 1, "s2_from_xwx: bad arguments");
     return s2_from_xwx(xwx, sig2_inv, s2, (size_t)len, (hipStream_t)stream);
+}
+
+int locus_hip_half_log_dev(const double* in, double* out, int64_t len, void* stream)
+{
+    LOCUS_REQUIRE(in && out && len >= 1, "half_log: bad arguments");
+    return half_log(in, out, (size_t)len, (hipStream_t)stream);
 }
 
 int locus_hip_logit_chi_psi_dev(const double* Q, const double* M, const double* Zmu,

@@ -63,6 +63,7 @@ struct SweepParams {
     const double* s2;     // [p][d]  sig2_beta_vb (response-contiguous)
     const double* xwx;    // [p][d]  sum_i X_ij^2 * 2 psi_ik
     const double* W2;     // [n x d] column-major: 2 * psi_vb
+    const double* ls2;    // [p][d]  log(sig2_beta_vb) / 2, or nullptr: the kernel takes the log
     double half_lsi;      // log_sig2_inv_vb / 2
     // in/out
     double* R;            // [n x d] column-major residual

@@ -24,6 +24,7 @@ int batch_update(double* state, const double* lo, const double* l1, const double
 int m2_minus_b2(const double* state, const double* s2jk, double s2c, double* D, size_t pd,
                 hipStream_t st);
 int s2_from_xwx(const double* xwx, double sig2_inv, double* s2, size_t len, hipStream_t st);
+int half_log(const double* in, double* out, size_t len, hipStream_t st);
 int logit_chi_psi(const double* Q, const double* M, const double* Zmu, const double* Y,
                   const double* Z, const double* s2a, const double* chi_old, const double* W2_old,
                   double* chi_new, double* W2_new, double* ey, int n, int d, int q, hipStream_t st);

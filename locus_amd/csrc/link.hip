@@ -92,6 +92,24 @@ int s2_from_xwx(const double* xwx, double sig2_inv, double* s2, size_t len, hipS
     return 0;
 }
 
+// out = log(in) / 2: log(sig2_beta_vb) / 2 of src/coreLoop.cpp:125, tabulated once per iteration
+// for the whole p x d matrix (HBM-bound) instead of inside the latency-bound sweep
+__global__ void __launch_bounds__(256) half_log_kernel(const double* __restrict__ in,
+                                                       double* __restrict__ out, size_t len)
+{
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < len;
+         e += (size_t)gridDim.x * blockDim.x)
+        out[e] = 0.5 * log(in[e]);
+}
+
+int half_log(const double* in, double* out, size_t len, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)std::min<size_t>((len + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(half_log_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, in, out, len);
+    LOCUS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Logit, one workgroup per response column k:
 //   c2      = Q + M^2 + Z^2 sig2_alpha + Zmu^2 + 2 M Zmu          (chi_vb^2, update_vb.R:165-166)

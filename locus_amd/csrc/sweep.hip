@@ -40,8 +40,9 @@ static int vgpr_estimate(int npl, int c, bool logit, bool wide = false)
 {
     // keep in step with sweep_depth() / sweep_max_threads() of sweep_kernel.h
     const int regs = 2 * npl * c * (logit ? 2 : 1);
-    if (wide) return regs + 16 * (regs <= 64 ? 4 : 2) + 90;
-    const int depth = regs <= 64 ? 6 : (regs <= 112 ? 4 : 2);
+    if (wide) return regs + 16 * ((regs <= 64 && !logit) ? 4 : 2) + 90;
+    const int depth = (logit && regs > 48) ? (regs <= 112 ? 4 : 2)
+                                           : (regs <= 64 ? 6 : (regs <= 112 ? 4 : 2));
     return regs + 8 * depth + 90;
 }
 

@@ -131,7 +131,9 @@ template <int NPL, int C, bool LOGIT, int PCS = kMaxPieces>
 constexpr int sweep_depth()
 {
     constexpr int regs = 2 * NPL * C * (LOGIT ? 2 : 1);
-    if (PCS > kMaxPieces) return regs <= 64 ? 4 : 2;  // 4 PCS registers per ring slot
+    // logit keeps four per-pair rings (beta_old, sig2_beta, xwx, log sig2_beta / 2) per slot
+    if (PCS > kMaxPieces) return (regs <= 64 && !LOGIT) ? 4 : 2;  // 4 PCS registers per ring slot
+    if (LOGIT && regs > 48) return regs <= 112 ? 4 : 2;
     return regs <= 64 ? 6 : (regs <= 112 ? 4 : 2);
 }
 
@@ -292,6 +294,8 @@ sweep_kernel(const SweepParams P)
     double bo_ring[D];
     double s2_ring[LOGIT ? D : 1];
     double xw_ring[LOGIT ? D : 1];
+    double lg_ring[LOGIT ? D : 1];   // log(sig2_beta_vb) / 2 when the caller tabulated it
+    const bool has_ls2 = LOGIT && P.ls2 != nullptr;   // uniform
 #pragma unroll
     for (int u = 0; u < D; ++u) {
         const size_t off = (size_t)steps[u].j * d + kls;
@@ -299,6 +303,7 @@ sweep_kernel(const SweepParams P)
         if constexpr (LOGIT) {
             s2_ring[u] = P.s2[off];
             xw_ring[u] = P.xwx[off];
+            lg_ring[u] = has_ls2 ? P.ls2[off] : 0.0;
         }
         // slot (u + 2) % D holds the column of step u + 2
         const double2* src =
@@ -393,8 +398,8 @@ sweep_kernel(const SweepParams P)
                 // :123-125, m^2 / (2 s2) + log(s2) / 2 without the library's division and log:
                 // the latency regime pays 8 issue cycles per instruction (sig2_beta_vb is a
                 // positive normal number)
-                a = st_lod - P.half_lsi - m * m * (0.5 * rcp_pos_normal(s2v)) -
-                    0.5 * log_pos_normal(s2v);
+                const double hl = has_ls2 ? lg_ring[u] : 0.5 * log_pos_normal(s2v);
+                a = st_lod - P.half_lsi - m * m * (0.5 * rcp_pos_normal(s2v)) - hl;
             } else {
                 const double2 k01 = *reinterpret_cast<const double2*>(mycons);
                 const double2 k23 = *reinterpret_cast<const double2*>(mycons + 2);
@@ -431,6 +436,7 @@ sweep_kernel(const SweepParams P)
                 if constexpr (LOGIT) {
                     s2_ring[u] = P.s2[off];
                     xw_ring[u] = P.xwx[off];
+                    if (has_ls2) lg_ring[u] = P.ls2[off];
                 }
             }
 

@@ -97,12 +97,15 @@ class Sweeper:
         self._keep = (shuffled_ind, lo, l1, scale, hinv, cst, s2k)
         _lib.check(_lib.lib().locus_hip_sweep_dev(ctypes.byref(a), 0, _stream()))
 
-    def logit(self, shuffled_ind, lo, l1, s2, xwx, W2, half_lsi, R, state, stats=None, nsteps=0):
-        """coreLogitLoop on the resident psi-weighted residual."""
+    def logit(self, shuffled_ind, lo, l1, s2, xwx, W2, half_lsi, R, state, stats=None, nsteps=0,
+              ls2=None):
+        """coreLogitLoop on the resident psi-weighted residual; ls2 = log(s2) / 2 (half_log)
+        spares the sweep one logarithm per (covariate, response) pair."""
         a = self._args(shuffled_ind, lo, l1, R, state, stats, nsteps)
         a.s2, a.xwx, a.W2 = s2.data_ptr(), xwx.data_ptr(), W2.data_ptr()
+        a.ls2 = ls2.data_ptr() if ls2 is not None else None
         a.half_lsi = float(half_lsi)
-        self._keep = (shuffled_ind, lo, l1, s2, xwx, W2)
+        self._keep = (shuffled_ind, lo, l1, s2, xwx, W2, ls2)
         _lib.check(_lib.lib().locus_hip_sweep_dev(ctypes.byref(a), 1, _stream()))
 
     def status(self):
@@ -169,6 +172,11 @@ def s2_from_xwx(xwx, sig2_inv, s2):
     _lib.check(_lib.lib().locus_hip_s2_from_xwx_dev(_p(xwx), float(sig2_inv), _p(s2), xwx.numel(),
                                                     _stream()))
     return s2
+
+
+def half_log(src, out):
+    _lib.check(_lib.lib().locus_hip_half_log_dev(_p(src), _p(out), src.numel(), _stream()))
+    return out
 
 
 def logit_chi_psi(Q, M, Zmu, Y, Z, s2a, chi_old, W2_old, chi_new, W2_new, ey, n, d, q):

@@ -118,6 +118,7 @@ class BinEngine:
             self.s2 = sig2_beta_vb if torch.is_tensor(sig2_beta_vb) else self._up(sig2_beta_vb)
             assert tuple(self.s2.shape) == (p, d)
             self.xwx = torch.empty((p, d), dtype=f64, device=device)
+            self.ls2 = torch.empty((p, d), dtype=f64, device=device)
             self.s2a = self._up(np.ascontiguousarray(sig2_alpha_vb, dtype=np.float64).reshape(q, d))
             self.chi = [cm(), cm()]
             self.W2 = [cm(), cm()]
@@ -193,12 +194,13 @@ class BinEngine:
             # xwx = crossprod(X^2, 2 psi) -> sig2_beta_vb = 1 / (xwx + sig2_inv_vb)
             dv.gemm(p, d, n, self.px.Xp, self.px.ld, 1, W2, 1, n, self.xwx, d, 1, sqA=True)
             dv.s2_from_xwx(self.xwx, host.sig2_inv_vb, self.s2)
+            dv.half_log(self.s2, self.ls2)          # log(sig2_beta_vb) / 2 for the sweep
             for i in order:
                 dv.alpha_step(self.Y, W2, self.M, self.Zmu, self.Zt[i], self.s2a[i], self.alpha[i],
                               n, d)
             dv.residual(self.Y, self.M, self.Zmu, W2, out=self.R, to_residual=True)
             self.sweeper.logit(ind, lo, l1, self.s2, self.xwx, W2, prm["log_sig2_inv_vb"] / 2,
-                               self.R, self.state)
+                               self.R, self.state, ls2=self.ls2)
             dv.residual(self.Y, self.R, self.Zmu, W2, out=self.M, to_residual=False)
         else:
             self.s2a_vec = U.update_sig2_alpha_vb_(n, host.zeta2_inv_vb, intercept=True)  # :63

@@ -73,7 +73,8 @@ class Sweeper:
             st[2] = (beta ** 2).sum(axis=0)
             st[3] = (R.numpy() ** 2).sum(axis=0)
 
-    def logit(self, shuffled_ind, lo, l1, s2, xwx, W2, half_lsi, R, state, stats=None, nsteps=0):
+    def logit(self, shuffled_ind, lo, l1, s2, xwx, W2, half_lsi, R, state, stats=None, nsteps=0,
+              ls2=None):
         if not self._check(shuffled_ind):
             return
         n, d = R.shape
@@ -154,6 +155,11 @@ def m2_minus_b2(state, p, d, D, s2jk=None, s2c=0.0):
 def s2_from_xwx(xwx, sig2_inv, s2):
     s2.numpy()[...] = 1.0 / (xwx.numpy() + sig2_inv)
     return s2
+
+
+def half_log(src, out):
+    out.numpy()[...] = 0.5 * np.log(src.numpy())
+    return out
 
 
 def logit_chi_psi(Q, M, Zmu, Y, Z, s2a, chi_old, W2_old, chi_new, W2_new, ey, n, d, q):

@@ -31,8 +31,8 @@ def test_header_symbols_exported_and_bound():
 
 def test_sweep_args_struct_matches_header():
     from locus_amd import _lib
-    # 3 int64 + 5 ptr + 4 ptr + double + 3 ptr + double + 3 ptr + ptr + 2 int64 + 4 int32
-    assert ctypes.sizeof(_lib.SweepArgs) == 8 * (3 + 5 + 4 + 1 + 3 + 1 + 3 + 1 + 2) + 16
+    # 3 int64 + 5 ptr + 4 ptr + double + 3 ptr + double + 3 ptr + ptr + 2 int64 + 4 int32 + ptr
+    assert ctypes.sizeof(_lib.SweepArgs) == 8 * (3 + 5 + 4 + 1 + 3 + 1 + 3 + 1 + 2) + 16 + 8
 
 
 @pytest.mark.parametrize("n,d", [(200, 20), (1000, 1000), (1000, 1250), (1000, 10000),
