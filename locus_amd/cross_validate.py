@@ -2,15 +2,16 @@
 and every value of the grid the model is fitted on the training rows by the device-resident
 drivers and the ELBO is evaluated on the held-out rows; the value with the best mean wins.
 
-Rebuilt for link = "identity", with or without fixed covariates Z (what the reference documents,
-R/cross_validate.R:11-12); the probit / mix branches (:345-383) raise NotImplementedError.
+Rebuilt for link = "identity" (with or without fixed covariates Z; what the reference documents,
+R/cross_validate.R:11-12) and for link = "probit" (:345-361); the mix branch (:363-383) raises
+NotImplementedError, logit is refused by the reference itself (R/prepare_locus.R:550-552).
 The reference spreads the folds over CPU cores (parallel::mclapply, :393); here fold k runs on
 rank k mod world when a communicator of several ranks is given (each rank fits whole folds on its
 own GPU), else the folds run one after the other.
 """
 import numpy as np
 
-from .prepare import auto_set_hyper_, auto_set_init_
+from .prepare import add_intercept_, auto_set_hyper_, auto_set_init_
 
 
 def create_grid_(p, size_p0_av_grid):
@@ -89,8 +90,9 @@ def cross_validate_(Y, X, Z, link, ind_bin, list_cv, user_seed, verbose, comm=No
                     _test_backend=None, perm_fn=None, alpha_perm_fn=None):
     """R/cross_validate.R:177-418.  Returns the selected p0_av; the matrix of held-out lower
     bounds (folds x grid) is left in list_cv["lb_mat"]."""
-    if link != "identity":
-        raise NotImplementedError("cross-validation is rebuilt for link = 'identity' only")
+    if link not in ("identity", "probit"):
+        raise NotImplementedError("cross-validation is rebuilt for link = 'identity' and 'probit'")
+    from .locus_bin_core import locus_probit_core_
     from .locus_core import locus_core_
     from .locus_z_core import locus_z_core_
     Y, X = np.asarray(Y, dtype=np.float64), np.asarray(X, dtype=np.float64)
@@ -112,8 +114,11 @@ def cross_validate_(Y, X, Z, link, ind_bin, list_cv, user_seed, verbose, comm=No
         cur = folds == k
         X_tr, X_test = _scale_train(X[~cur], X[cur])
         p = X_tr.shape[1]
-        Y_tr = np.asfortranarray(Y[~cur] - Y[~cur].mean(axis=0))
-        Y_test = np.asfortranarray(Y[cur] - Y[cur].mean(axis=0))
+        if link == "identity":                                  # :211-222
+            Y_tr = np.asfortranarray(Y[~cur] - Y[~cur].mean(axis=0))
+            Y_test = np.asfortranarray(Y[cur] - Y[cur].mean(axis=0))
+        else:
+            Y_tr, Y_test = np.asfortranarray(Y[~cur]), np.asfortranarray(Y[cur])
         q = Z_tr = Z_test = None
         if Z is not None:
             Z_tr, Z_test = _scale_train(np.asarray(Z, dtype=np.float64)[~cur],
@@ -124,7 +129,15 @@ def cross_validate_(Y, X, Z, link, ind_bin, list_cv, user_seed, verbose, comm=No
                 print(f"Evaluating p0_av = {pg:g}... ")
             hy = auto_set_hyper_(Y_tr, p, pg, q=q, link=link)
             li = auto_set_init_(Y_tr, p, pg, q=q, user_seed=user_seed, link=link)
-            if q is None:
+            if link == "probit":                                 # :258-300, :345-361
+                Zi_tr = add_intercept_(X_tr.shape[0], d, hy, li, link, Z_tr)
+                one = np.ones((X_test.shape[0], 1))
+                Zi_test = one if Z_test is None else np.hstack([one, Z_test])
+                vb = locus_probit_core_(Y_tr, X_tr, Zi_tr, hy, li["gam_vb"], li["alpha_vb"],
+                                        li["mu_beta_vb"], li["sig2_alpha_vb"], li["sig2_beta_vb"],
+                                        held_out=(Y_test, X_test, Zi_test),
+                                        alpha_perm_fn=alpha_perm_fn, **kw)
+            elif q is None:
                 vb = locus_core_(Y_tr, X_tr, hy, li["gam_vb"], li["mu_beta_vb"], li["sig2_beta_vb"],
                                  li["tau_vb"], held_out=(Y_test, X_test), **kw)
             else:

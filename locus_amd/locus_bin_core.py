@@ -227,6 +227,7 @@ class BinEngine:
         sums = t.cat([rows[1:].sum(dim=1), self.ey.sum().reshape(1)]).cpu().numpy()
         self.sweeper.status()
         ent, gls, sum_m2, ey = (float(v) for v in sums)
+        self._ey_fit = ey
         rs_m2a, sum_log_s2a = self._m2_alpha_rows()
         rs_gam_loc_sum = float(rows[0].sum().item())
         # shard-local sums of the ELBO: e_y_*, and of e_beta_gamma_bin_ the terms
@@ -240,6 +241,31 @@ class BinEngine:
             fn = lambda lz: E.e_alpha_probit_(host.rs_m2_alpha, self.s2a_vec, q, host.d, lz,  # noqa: E731
                                               host.zeta2_inv_vb)
         return host.finish_elbo(float(tot[0]), fn)
+
+    def held_out_elbo(self, lb_fit, Y_test_loc, X_test, Z_test):
+        """elbo_probit_ on held-out rows (R/cross_validate.R:345-361).  Of its six terms only
+        e_y_probit_ (R/elbo.R:221-237) sees the data, so the held-out bound is the fitted one with
+        that term re-evaluated on (Y_test, X_test, Z_test): X_test beta_vb and
+        X_test^2 (m2_beta - beta_vb^2) on the matrix cores, then the probit_w kernel."""
+        if self.link != "probit":
+            raise NotImplementedError("held-out ELBO: probit only (R/prepare_locus.R:550-552)")
+        t, dv = self.torch, self.dv
+        p, d = self.p, self.d_loc
+        Zt = np.asarray(Z_test, dtype=np.float64)
+        nt = Zt.shape[0]
+        Xt = dv.to_device_colmajor(X_test, self.device)
+        Yt = dv.to_device_colmajor(Y_test_loc, self.device)
+        cm = lambda: t.empty((d, nt), dtype=t.float64, device=self.device).t()  # noqa: E731
+        M, Q, W = cm(), cm(), cm()
+        dv.gemm(nt, d, p, Xt, 1, nt, self.state[2], d, 1, M, 1, nt)
+        dv.gemm(nt, d, p, Xt, 1, nt, self.D, d, 1, Q, 1, nt, sqA=True)   # D of the last iteration
+        Zmu = self._up((Zt @ self.alpha.cpu().numpy()).T).t()
+        zs = self._up((Zt ** 2) @ self.s2a_vec)
+        ey = t.empty((d,), dtype=t.float64, device=self.device)
+        dv.probit_w(Yt, M, Zmu, Q, zs, W, ey, nt, d)
+        delta = (ey.sum() - self._ey_fit).reshape(1)
+        self.host.comm.all_reduce_sum_(delta)
+        return lb_fit + float(delta.item())
 
     def download(self):
         out = LazyFields(gam_vb=lambda: to_host_F(self.state[0]),
@@ -258,7 +284,7 @@ class BinEngine:
 
 def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb, sig2_beta_vb,
          tol, maxit, verbose, batch, full_output, debug, perm_fn, alpha_perm_fn, comm, device,
-         trace, _test_backend):
+         trace, _test_backend, held_out=None):
     dv, device = resolve_backend(_test_backend, device)
     import torch
     if batch != "y":
@@ -311,6 +337,9 @@ def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
     out = dict(beta_vb=g("beta_vb"), gam_vb=g("gam_vb"), om_vb=host.om_vb,
                alpha_vb=g("alpha_vb"), converged=converged, it=it, lb_opt=lb_new,
                diff_lb=abs(lb_new - lb_old))
+    if held_out is not None:
+        Yt = np.asarray(held_out[0], dtype=np.float64)
+        out["lb_held_out"] = eng.held_out_elbo(lb_new, Yt[:, k_lo:k_hi], held_out[1], held_out[2])
     if full_output:
         out.update(mu_beta_vb=g("mu_beta_vb"), mat_x_m1=g("mat_x_m1"), mat_z_mu=g("mat_z_mu"),
                    sig2_inv_vb=host.sig2_inv_vb, zeta2_inv_vb=host.zeta2_inv_vb,
@@ -339,9 +368,10 @@ def locus_logit_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_al
 def locus_probit_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
                        sig2_beta_vb, tol, maxit, verbose=False, batch="y", full_output=False,
                        debug=False, perm_fn=None, alpha_perm_fn=None, comm=None, device=None,
-                       trace=None, _test_backend=None):
+                       trace=None, held_out=None, _test_backend=None):
     """R/locus_probit_core.R:8-250 on the GPU.  Y is 0/1, Z[:, 0] is the intercept (:13);
-    sig2_alpha_vb is a length-q vector and sig2_beta_vb a scalar."""
+    sig2_alpha_vb is a length-q vector and sig2_beta_vb a scalar.  `held_out = (Y_test, X_test,
+    Z_test)` adds `lb_held_out` (R/cross_validate.R:345-361)."""
     return _run("probit", Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
                 sig2_beta_vb, tol, maxit, verbose, batch, full_output, debug, perm_fn,
-                alpha_perm_fn, comm, device, trace, _test_backend)
+                alpha_perm_fn, comm, device, trace, _test_backend, held_out)

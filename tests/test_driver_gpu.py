@@ -409,3 +409,30 @@ def test_identity_c1_elbo_trace_against_golden(hip):
     assert r["it"] == int(f["it"]) and r["converged"]
     np.testing.assert_allclose([x[1] for x in tr], f["elbo_trace"], rtol=1e-8)
     np.testing.assert_array_equal(np.argwhere(r["gam_vb"] > 0.5), f["selected"])
+
+
+def test_cross_validation_probit_on_gpu(oracle, hip):
+    """The probit branch of cross_validate_ (R/cross_validate.R:258-300, 345-361) on the device:
+    the held-out bound re-evaluates e_y_probit_ with two MFMA contractions over the test rows."""
+    from oracle import ref_driver
+    from locus_amd.cross_validate import cross_validate_, set_cv
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_, prepare_data_
+    from locus_amd.simulate import simulate
+    n, p, d = 150, 100, 9
+    sim = simulate(n, p, d, 8, seed=33, link="probit")
+    Yb, Xs, _ = prepare_data_(sim["Y"], sim["X"], link="probit")
+    Z = np.random.default_rng(3).normal(size=(n, 2))
+    cv = set_cv(n, p, n_folds=3, size_p0_av_grid=3, maxit_cv=4, verbose=False)
+    cv["p0_av_grid"], cv["tol_cv"] = np.array([4.0, 10.0, 30.0]), 1e-30
+    perm_fn = lambda it: np.random.default_rng(70 + it).permutation(p).astype(np.float64)  # noqa: E731
+    aperm = lambda it: np.arange(3)  # noqa: E731
+
+    def defaults(Y_tr, pp, pg, q):
+        return (auto_set_hyper_(Y_tr, pp, pg, q=q, link="probit"),
+                auto_set_init_(Y_tr, pp, pg, q=q, user_seed=5, link="probit"))
+    ref_opt, ref_lb = ref_driver.cross_validate_(Yb, Xs, Z, cv, defaults, perm_fn, link="probit",
+                                                 alpha_perm_fn=aperm)
+    got_opt = cross_validate_(Yb, Xs, Z, "probit", None, cv, 5, False, perm_fn=perm_fn,
+                              alpha_perm_fn=aperm)
+    np.testing.assert_allclose(cv["lb_mat"], ref_lb, rtol=1e-8)
+    assert got_opt == ref_opt

@@ -138,6 +138,41 @@ def test_cross_validation_matches_restatement(oracle, with_z):
         locus(sim["Y"], X, 5, list_cv=cv, verbose=False, _test_backend=cpu_device)
 
 
+@pytest.mark.parametrize("with_z", [False, True])
+def test_cross_validation_probit_matches_restatement(oracle, with_z):
+    """The probit branch of cross_validate_ (R/cross_validate.R:258-300, 345-361)."""
+    import cpu_device
+    from oracle import ref_driver
+    from locus_amd.cross_validate import cross_validate_, set_cv
+    from locus_amd.locus import locus
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_, prepare_data_
+    sim, X = _data("probit")
+    Yb, Xs, _ = prepare_data_(sim["Y"], X, link="probit")
+    Z = np.random.default_rng(3).normal(size=(N, 2)) if with_z else None
+    q = 2 if with_z else None
+    cv = set_cv(N, X.shape[1], n_folds=3, size_p0_av_grid=3, maxit_cv=3, verbose=False)
+    cv["p0_av_grid"], cv["tol_cv"] = np.array([3.0, 8.0, 20.0]), 1e-30
+    perm_fn = lambda it: np.random.default_rng(70 + it).permutation(60).astype(np.float64)  # noqa: E731
+    aperm = lambda it: np.arange(1 + (q or 0))  # noqa: E731
+
+    def defaults(Y_tr, p, pg, qq):
+        return (auto_set_hyper_(Y_tr, p, pg, q=qq, link="probit"),
+                auto_set_init_(Y_tr, p, pg, q=qq, user_seed=5, link="probit"))
+    ref_opt, ref_lb = ref_driver.cross_validate_(Yb, Xs, Z, cv, defaults, perm_fn, link="probit",
+                                                 alpha_perm_fn=aperm)
+    got_opt = cross_validate_(Yb, Xs, Z, "probit", None, cv, 5, False, _test_backend=cpu_device,
+                              perm_fn=perm_fn, alpha_perm_fn=aperm)
+    np.testing.assert_allclose(cv["lb_mat"], ref_lb, rtol=1e-8)
+    assert got_opt == ref_opt
+    cv = set_cv(N, X.shape[1], n_folds=2, size_p0_av_grid=2, tol_cv=1.0, maxit_cv=4, verbose=False)
+    vb = locus(sim["Y"], X, None, Z=Z, link="probit", list_cv=cv, user_seed=5, maxit=2,
+               verbose=False, _test_backend=cpu_device)
+    assert vb["p_star"] in cv["p0_av_grid"]
+    with pytest.raises(ValueError):                                        # R/prepare_locus.R:550
+        locus(sim["Y"] - 0.0, X, None, link="logit", list_cv=cv, verbose=False,
+              _test_backend=cpu_device)
+
+
 def test_duplicated_columns_match_lexicographic_unique():
     """prepare._duplicated_columns (hash + exact check) against numpy's sort-based unique, the
     semantics of R's duplicated(X, MARGIN = 2): every copy after the first is flagged."""
