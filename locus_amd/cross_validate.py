@@ -2,9 +2,9 @@
 and every value of the grid the model is fitted on the training rows by the device-resident
 drivers and the ELBO is evaluated on the held-out rows; the value with the best mean wins.
 
-Rebuilt for link = "identity" (with or without fixed covariates Z; what the reference documents,
-R/cross_validate.R:11-12) and for link = "probit" (:345-361); the mix branch (:363-383) raises
-NotImplementedError, logit is refused by the reference itself (R/prepare_locus.R:550-552).
+All the links the reference's procedure covers: "identity" with or without fixed covariates Z
+(R/cross_validate.R:303-343), "probit" (:345-361) and "mix" (:363-383); logit is refused by the
+reference itself (R/prepare_locus.R:550-552).
 The reference spreads the folds over CPU cores (parallel::mclapply, :393); here fold k runs on
 rank k mod world when a communicator of several ranks is given (each rank fits whole folds on its
 own GPU), else the folds run one after the other.
@@ -90,9 +90,10 @@ def cross_validate_(Y, X, Z, link, ind_bin, list_cv, user_seed, verbose, comm=No
                     _test_backend=None, perm_fn=None, alpha_perm_fn=None):
     """R/cross_validate.R:177-418.  Returns the selected p0_av; the matrix of held-out lower
     bounds (folds x grid) is left in list_cv["lb_mat"]."""
-    if link not in ("identity", "probit"):
-        raise NotImplementedError("cross-validation is rebuilt for link = 'identity' and 'probit'")
+    if link not in ("identity", "probit", "mix"):
+        raise ValueError("cross-validation: link must be 'identity', 'probit' or 'mix'")
     from .locus_bin_core import locus_probit_core_
+    from .locus_mix_core import locus_mix_core_
     from .locus_core import locus_core_
     from .locus_z_core import locus_z_core_
     Y, X = np.asarray(Y, dtype=np.float64), np.asarray(X, dtype=np.float64)
@@ -117,6 +118,11 @@ def cross_validate_(Y, X, Z, link, ind_bin, list_cv, user_seed, verbose, comm=No
         if link == "identity":                                  # :211-222
             Y_tr = np.asfortranarray(Y[~cur] - Y[~cur].mean(axis=0))
             Y_test = np.asfortranarray(Y[cur] - Y[cur].mean(axis=0))
+        elif link == "mix":
+            cont = np.setdiff1d(np.arange(d), ind_bin)
+            Y_tr, Y_test = np.array(Y[~cur], order="F"), np.array(Y[cur], order="F")
+            Y_tr[:, cont] -= Y_tr[:, cont].mean(axis=0)
+            Y_test[:, cont] -= Y_test[:, cont].mean(axis=0)
         else:
             Y_tr, Y_test = np.asfortranarray(Y[~cur]), np.asfortranarray(Y[cur])
         q = Z_tr = Z_test = None
@@ -127,12 +133,18 @@ def cross_validate_(Y, X, Z, link, ind_bin, list_cv, user_seed, verbose, comm=No
         for g, pg in enumerate(grid):
             if verbose:
                 print(f"Evaluating p0_av = {pg:g}... ")
-            hy = auto_set_hyper_(Y_tr, p, pg, q=q, link=link)
-            li = auto_set_init_(Y_tr, p, pg, q=q, user_seed=user_seed, link=link)
-            if link == "probit":                                 # :258-300, :345-361
+            hy = auto_set_hyper_(Y_tr, p, pg, q=q, link=link, ind_bin=ind_bin)
+            li = auto_set_init_(Y_tr, p, pg, q=q, user_seed=user_seed, link=link, ind_bin=ind_bin)
+            if link != "identity":                               # intercept, :258-300
                 Zi_tr = add_intercept_(X_tr.shape[0], d, hy, li, link, Z_tr)
                 one = np.ones((X_test.shape[0], 1))
                 Zi_test = one if Z_test is None else np.hstack([one, Z_test])
+            if link == "mix":                                    # :363-383
+                vb = locus_mix_core_(Y_tr, X_tr, Zi_tr, ind_bin, hy, li["gam_vb"], li["alpha_vb"],
+                                     li["mu_beta_vb"], li["sig2_alpha_vb"], li["sig2_beta_vb"],
+                                     li["tau_vb"], held_out=(Y_test, X_test, Zi_test),
+                                     alpha_perm_fn=alpha_perm_fn, **kw)
+            elif link == "probit":                               # :345-361
                 vb = locus_probit_core_(Y_tr, X_tr, Zi_tr, hy, li["gam_vb"], li["alpha_vb"],
                                         li["mu_beta_vb"], li["sig2_alpha_vb"], li["sig2_beta_vb"],
                                         held_out=(Y_test, X_test, Zi_test),

@@ -4,7 +4,7 @@ default hyper-parameters and initial values when none are given, dispatches on l
 list_struct to the device-resident drivers and returns the reference's `vb` fields.
 
 `list_cv` (set_cv): p0_av is chosen by cross-validation on the held-out ELBO
-(locus_amd.cross_validate, R/cross_validate.R) for the identity and probit links.
+(locus_amd.cross_validate, R/cross_validate.R) for the identity, probit and mix links (logit is refused, as in R/prepare_locus.R:550-552).
 
 Not rebuilt (out of scope): group selection (list_groups); asking for it raises
 NotImplementedError rather than silently doing something else.

@@ -83,6 +83,7 @@ class MixHost(IdentityHost):
         - Q / 2  (device); zz = colSums(Z^2)."""
         n, d, q, dc = self.n, self.d, self.q, self.dc
         self.stats = np.asarray(stats, dtype=np.float64)
+        self._last = (rs_gam_local, ent_local, alpha_vb)
         cs_gam, cs_m2, cs_b2, rss = self.stats
         self.alpha = np.asarray(alpha_vb, dtype=np.float64).reshape(q, -1)
         self.m2_alpha = U.update_m2_alpha_(self.alpha, self.sig2_alpha_vb)
@@ -112,6 +113,20 @@ class MixHost(IdentityHost):
                      + E.e_sig2_inv_(self.lam, lambda_vb, log_sig2_inv_vb, self.nu, nu_vb, si)
                      + e_om + 0.5 * d * float(np.sum(log_zeta2_inv_vb))
                      + E.e_zeta2_inv_(log_zeta2_inv_vb, self.phi, self.phi_vb, self.xi, xi_vb, zi))
+
+
+    def held_out_elbo_mix_(self, n_test, rss_test, ey_bin_test, zz_test):
+        """elbo_mix_ (R/locus_mix_core.R:287-349) with the held-out rows' n, residual sums of
+        squares (continuous responses), e_y_probit_ sum (binary ones) and colSums(Z_test^2);
+        everything else as fitted (R/cross_validate.R:363-383)."""
+        n_fit, st_fit = self.n, self.stats
+        try:
+            self.n = int(n_test)
+            st = st_fit.copy()
+            st[3] = rss_test
+            return self.end_iteration(st, *self._last, ey_bin_test, zz_test)
+        finally:
+            self.n, self.stats = n_fit, st_fit
 
 
 class MixEngine(IdentityEngine):
@@ -189,6 +204,33 @@ class MixEngine(IdentityEngine):
         return self.host.end_iteration(h[: 4 * d].reshape(4, d), rs_gam, float(h[4 * d]),
                                        h[4 * d + 1:], ey_bin, self.zz)
 
+    def held_out_elbo_mix(self, Y_test_loc, X_test, Z_test):
+        """Y_test_loc in the local [continuous | binary] order (continuous columns centred)."""
+        t, dv = self.torch, self.dv
+        p, d, dc, db = self.p, self.d_loc, self.dc, self.db
+        Zt = np.asarray(Z_test, dtype=np.float64)
+        nt = Zt.shape[0]
+        Xt = dv.to_device_colmajor(X_test, self.device)
+        Yt = dv.to_device_colmajor(Y_test_loc, self.device)
+        cm = lambda k: t.empty((k, nt), dtype=t.float64, device=self.device).t()  # noqa: E731
+        M = cm(d)
+        dv.gemm(nt, d, p, Xt, 1, nt, self.state[2], d, 1, M, 1, nt)
+        Zmu = self._up((Zt @ self.alpha.cpu().numpy()).T).t()
+        R = dv.residual(Yt, M, Zmu)
+        rss = (R * R).sum(dim=0).cpu().numpy()
+        ey = 0.0
+        if db > 0:
+            s2 = self._up(self.host.sig2_beta_vb[dc:])
+            g, m, b = (self.state[k][:, dc:] for k in range(3))
+            D = (g * (m * m + s2) - b * b).contiguous()
+            Q, W = cm(db), cm(db)
+            eyv = t.zeros((db,), dtype=t.float64, device=self.device)
+            dv.gemm(nt, db, p, Xt, 1, nt, D, db, 1, Q, 1, nt, sqA=True)
+            dv.probit_w(Yt[:, dc:], M[:, dc:], Zmu[:, dc:], Q,
+                        t.zeros((nt,), dtype=t.float64, device=self.device), W, eyv, nt, db)
+            ey = float(eyv.sum().item())
+        return self.host.held_out_elbo_mix_(nt, rss, ey, (Zt ** 2).sum(axis=0))
+
     def download(self):
         out = LazyFields(gam_vb=lambda: to_host_F(self.state[0]),
                          mu_beta_vb=lambda: to_host_F(self.state[1]),
@@ -201,8 +243,9 @@ class MixEngine(IdentityEngine):
 def locus_mix_core_(Y, X, Z, ind_bin, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
                     sig2_beta_vb, tau_vb, tol, maxit, verbose=False, batch="y", full_output=False,
                     debug=False, perm_fn=None, alpha_perm_fn=None, comm=None, device=None,
-                    trace=None, _test_backend=None):
-    """R/locus_mix_core.R:8-280 on the GPU.  `ind_bin`: 0-based indices of the binary (0/1)
+                    trace=None, held_out=None, _test_backend=None):
+    """R/locus_mix_core.R:8-280 on the GPU.  `held_out = (Y_test, X_test, Z_test)` adds
+    `lb_held_out` (R/cross_validate.R:363-383).  `ind_bin`: 0-based indices of the binary (0/1)
     responses of Y; the continuous ones are centred, X and Z[:, 1:] standardised, Z[:, 0] is the
     intercept.  eta, kappa of list_hyper have one entry per continuous response (in order);
     tau_vb has length d with 1 at the binary responses."""
@@ -274,6 +317,9 @@ def locus_mix_core_(Y, X, Z, ind_bin, list_hyper, gam_vb, alpha_vb, mu_beta_vb, 
     out = dict(beta_vb=gather(loc_out["beta_vb"]), gam_vb=gather(loc_out["gam_vb"]),
                om_vb=host.om_vb, alpha_vb=gather(loc_out["alpha_vb"]), converged=converged, it=it,
                lb_opt=lb_new, diff_lb=abs(lb_new - lb_old))
+    if held_out is not None:
+        Yt = np.asarray(held_out[0], dtype=np.float64)
+        out["lb_held_out"] = eng.held_out_elbo_mix(Yt[:, order], held_out[1], held_out[2])
     if full_output:                                                      # :264-270
         out.update(mu_beta_vb=gather(loc_out["mu_beta_vb"]), mat_x_m1=gather(loc_out["mat_x_m1"]),
                    mat_z_mu=gather(loc_out["mat_z_mu"]), sig2_alpha_vb=gather(host.sig2_alpha_vb),

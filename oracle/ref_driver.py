@@ -1080,7 +1080,8 @@ def locus_mix_core_(Y, X, Z, ind_bin, list_hyper, gam_vb, alpha_vb, mu_beta_vb, 
     return dict(beta_vb=beta_vb, gam_vb=gam_vb, om_vb=om_vb, alpha_vb=alpha_vb,
                 converged=converged, it=it, lb_opt=lb_new, diff_lb=abs(lb_new - lb_old),
                 mu_beta_vb=mu_beta_vb, mat_x_m1=mat_x_m1, mat_z_mu=mat_z_mu,
-                sig2_alpha_vb=sig2_alpha_vb, sig2_beta_vb=sig2_beta_vb, tau_vb=tau_vb)
+                sig2_alpha_vb=sig2_alpha_vb, sig2_beta_vb=sig2_beta_vb, tau_vb=tau_vb,
+                sig2_inv_vb=sig2_inv_vb, zeta2_inv_vb=zeta2_inv_vb)
 
 
 # --------------------------------------------------------------------------- #
@@ -1109,9 +1110,9 @@ def sweep_identity_scalar_R(X, Y, gam_vb, log_om_vb, log_1_min_om_vb, log_sig2_i
 # R/cross_validate.R
 # --------------------------------------------------------------------------- #
 def cross_validate_(Y, X, Z, list_cv, set_hyper_init, perm_fn, link="identity",
-                    alpha_perm_fn=None):
-    """R/cross_validate.R:177-418 for link = "identity" / "probit" (full matrices, folds one after
-    the other).  `set_hyper_init(Y_tr, p, pg, q)` returns (list_hyper, list_init) -- the defaults of
+                    alpha_perm_fn=None, ind_bin=None):
+    """R/cross_validate.R:177-418 for link = "identity" / "probit" / "mix" (full matrices, folds
+    one after the other; ind_bin 0-based).  `set_hyper_init(Y_tr, p, pg, q)` returns (list_hyper, list_init) -- the defaults of
     R/set_hyper_init.R, whose random draws the caller controls.  Returns (p0_av_opt, lb_mat)."""
     n, d = Y.shape
     grid = np.asarray(list_cv["p0_av_grid"], dtype=np.float64)
@@ -1132,6 +1133,11 @@ def cross_validate_(Y, X, Z, list_cv, set_hyper_init, perm_fn, link="identity",
         if link == "identity":
             Y_tr = Y[~cur] - Y[~cur].mean(axis=0)                        # :214-215
             Y_test = Y[cur] - Y[cur].mean(axis=0)
+        elif link == "mix":                                              # :217-222
+            cont = np.setdiff1d(np.arange(d), ind_bin)
+            Y_tr, Y_test = Y[~cur].copy(), Y[cur].copy()
+            Y_tr[:, cont] -= Y_tr[:, cont].mean(axis=0)
+            Y_test[:, cont] -= Y_test[:, cont].mean(axis=0)
         else:
             Y_tr, Y_test = Y[~cur], Y[cur]
         q = None
@@ -1142,7 +1148,35 @@ def cross_validate_(Y, X, Z, list_cv, set_hyper_init, perm_fn, link="identity",
             hy, li = set_hyper_init(Y_tr, p, pg, q)
             kw = dict(tol=list_cv["tol_cv"], maxit=list_cv["maxit_cv"], perm_fn=perm_fn)
             a, b = np.broadcast_to(hy["a"], (p,)), np.broadcast_to(hy["b"], (p,))
-            if link == "probit":                                         # :258-300, :345-361
+            if link == "mix":                                            # :258-300, :363-383
+                one_tr, one_te = np.ones((X_tr.shape[0], 1)), np.ones((X_test.shape[0], 1))
+                if q is None:
+                    Zi_tr, Zi_te = one_tr, one_te
+                    phi = xi = np.array([1e-3])
+                    al0, s2a0 = np.zeros((1, d)), np.ones((1, d))
+                else:
+                    Zi_tr, Zi_te = np.hstack([one_tr, Z_tr]), np.hstack([one_te, Z_test])
+                    phi = np.concatenate([[1e-3], np.broadcast_to(hy["phi"], (q,))])
+                    xi = np.concatenate([[1e-3], np.broadcast_to(hy["xi"], (q,))])
+                    al0 = np.vstack([np.zeros((1, d)), li["alpha_vb"]])
+                    s2a0 = np.vstack([np.ones((1, d)), li["sig2_alpha_vb"]])
+                hy = dict(hy, phi=phi, xi=xi)
+                vb = locus_mix_core_(Y_tr, X_tr, Zi_tr, ind_bin, hy, li["gam_vb"].copy(), al0,
+                                     li["mu_beta_vb"].copy(), s2a0, li["sig2_beta_vb"],
+                                     li["tau_vb"], alpha_perm_fn=alpha_perm_fn, **kw)
+                rs = vb["gam_vb"].sum(axis=1)
+                m2_beta = update_m2_beta_(vb["gam_vb"], vb["mu_beta_vb"], vb["sig2_beta_vb"],
+                                          sweep=True)
+                m2_alpha = update_m2_alpha_(vb["alpha_vb"], vb["sig2_alpha_vb"])
+                lb_mat[k, g] = elbo_mix_(
+                    Y_test[:, ind_bin], Y_test[:, cont], ind_bin, X_test, Zi_te, a,
+                    update_a_vb(a, rs), b, update_b_vb(b, d, rs), vb["beta_vb"], hy["eta"],
+                    vb["gam_vb"], hy["kappa"], hy["lambda"], vb["alpha_vb"], hy["nu"], phi,
+                    update_phi_z_vb_(phi, d), vb["sig2_alpha_vb"], vb["sig2_beta_vb"],
+                    vb["sig2_inv_vb"], vb["tau_vb"], np.zeros(d), xi, vb["zeta2_inv_vb"], m2_alpha,
+                    m2_beta, X_test @ vb["beta_vb"], Zi_te @ vb["alpha_vb"],
+                    float(vb["gam_vb"].sum()))
+            elif link == "probit":                                       # :258-300, :345-361
                 one_tr, one_te = np.ones((X_tr.shape[0], 1)), np.ones((X_test.shape[0], 1))
                 if q is None:
                     Zi_tr, Zi_te = one_tr, one_te

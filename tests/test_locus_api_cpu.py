@@ -173,6 +173,36 @@ def test_cross_validation_probit_matches_restatement(oracle, with_z):
               _test_backend=cpu_device)
 
 
+@pytest.mark.parametrize("with_z", [False, True])
+def test_cross_validation_mix_matches_restatement(oracle, with_z):
+    """The mix branch of cross_validate_ (R/cross_validate.R:217-222, 258-300, 363-383)."""
+    import cpu_device
+    from oracle import ref_driver
+    from locus_amd.cross_validate import cross_validate_, set_cv
+    from locus_amd.prepare import auto_set_hyper_, auto_set_init_, prepare_data_
+    sim, X = _data()
+    ind_bin = np.array([1, 4])
+    Yb = sim["Y"].copy()
+    Yb[:, ind_bin] = (Yb[:, ind_bin] > 0).astype(np.float64)
+    Ym, Xs, _ = prepare_data_(Yb, X, link="mix", ind_bin=ind_bin)
+    Z = np.random.default_rng(3).normal(size=(N, 2)) if with_z else None
+    q = 2 if with_z else None
+    cv = set_cv(N, X.shape[1], n_folds=3, size_p0_av_grid=3, maxit_cv=3, verbose=False)
+    cv["p0_av_grid"], cv["tol_cv"] = np.array([3.0, 8.0, 20.0]), 1e-30
+    perm_fn = lambda it: np.random.default_rng(70 + it).permutation(60).astype(np.float64)  # noqa: E731
+    aperm = lambda it: np.arange(1 + (q or 0))  # noqa: E731
+
+    def defaults(Y_tr, p, pg, qq):
+        return (auto_set_hyper_(Y_tr, p, pg, q=qq, link="mix", ind_bin=ind_bin),
+                auto_set_init_(Y_tr, p, pg, q=qq, user_seed=5, link="mix", ind_bin=ind_bin))
+    ref_opt, ref_lb = ref_driver.cross_validate_(Ym, Xs, Z, cv, defaults, perm_fn, link="mix",
+                                                 alpha_perm_fn=aperm, ind_bin=ind_bin)
+    got_opt = cross_validate_(Ym, Xs, Z, "mix", ind_bin, cv, 5, False, _test_backend=cpu_device,
+                              perm_fn=perm_fn, alpha_perm_fn=aperm)
+    np.testing.assert_allclose(cv["lb_mat"], ref_lb, rtol=1e-8)
+    assert got_opt == ref_opt
+
+
 def test_duplicated_columns_match_lexicographic_unique():
     """prepare._duplicated_columns (hash + exact check) against numpy's sort-based unique, the
     semantics of R's duplicated(X, MARGIN = 2): every copy after the first is flagged."""
