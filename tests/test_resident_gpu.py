@@ -85,3 +85,22 @@ def test_locus_core_through_the_resident_context(oracle, hip, anneal):
     np.testing.assert_allclose(got["om_vb"], ref["om_vb"], rtol=1e-9)
     assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
     assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+
+
+def test_c_abi_from_a_plain_c_program(hip):
+    """tests/c/abi_smoke.c: the stateless coreLoop entry point and the resident context called
+    from C (gcc, no Python in the data path), cross-checked against each other."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = os.path.join(here, "c", "abi_smoke")
+    if not os.path.exists(exe):                       # normally built by __graft_entry__.build()
+        subprocess.check_call(["gcc", "-O1", "-I", os.path.join(root, "include"),
+                               os.path.join(here, "c", "abi_smoke.c"), "-o", exe,
+                               "-L", os.path.join(root, "locus_amd"), "-llocus_hip", "-lm",
+                               "-Wl,-rpath," + os.path.join(root, "locus_amd")])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "locus_amd") + ":" +
+               os.environ.get("LD_LIBRARY_PATH", ""))
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=100, env=env)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
