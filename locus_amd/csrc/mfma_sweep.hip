@@ -102,8 +102,10 @@ pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ st
 // row tiles of 16 per matrix wave for n rows: the instantiated KT values
 int mfma_kt_for(int64_t n, int T)
 {
-    static const int kts2[] = {2, 4, 6, 9, 0};         // instantiated for T = 2 (7 matrix waves)
-    static const int kts1[] = {2, 4, 6, 8, 11, 21, 0};  // T = 1 (6 matrix waves)
+#define LOCUS_KT_ITEM(k) k,
+    static const int kts2[] = {LOCUS_MFMA_KTS_T2(LOCUS_KT_ITEM) 0};  // T = 2 (7 matrix waves)
+    static const int kts1[] = {LOCUS_MFMA_KTS_T1(LOCUS_KT_ITEM) 0};  // T = 1 (6 matrix waves)
+#undef LOCUS_KT_ITEM
     for (const int* kt = (T == 2) ? kts2 : kts1; *kt; ++kt)
         if ((int64_t)mfma_waves(T) * 16 * *kt >= n) return *kt;
     return 0;

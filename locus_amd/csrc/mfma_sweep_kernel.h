@@ -78,6 +78,14 @@ __host__ __device__ constexpr int op_index(int i, int c, int KT)
     return (2 * ip + 1 < KT) ? 8 * ip + 2 * c + (i & 1) : 8 * ip + c;
 }
 
+// 16-row tiles per matrix wave (KT) the library instantiates, per T: fine steps so that the row
+// padding 16 KT MW - n stays small for any n (n = 1500 needs KT = 16 at T = 1, not 21).  Values
+// whose 4 KT has no divisor near the ring cap (13, 17, 19, 20) are left out.  One list for the
+// host-side choice (mfma_sweep.hip) and the dispatch (mfma_sweep_inst.inc).
+#define LOCUS_MFMA_KTS_T1(X) \
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(14) X(15) X(16) X(18) X(21)
+#define LOCUS_MFMA_KTS_T2(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
+
 struct MfmaSweepParams {
     int n, p, d;
     int k_begin, k_end;  // responses [k_begin, k_end) of the d columns are swept by this launch
@@ -115,7 +123,7 @@ constexpr int ring_pairs()
 #if defined(LOCUS_RING_T1) && defined(LOCUS_RING_T2)
     constexpr int cap = (T == 1) ? LOCUS_RING_T1 : LOCUS_RING_T2;
 #else
-    constexpr int cap = (T == 1) ? 12 : 6;
+    constexpr int cap = (T == 1) ? (KT > 18 ? 7 : 12) : 6;  // KT = 21: 168 residual registers
 #endif
     int best = 1;
     for (int r = 1; r <= cap; ++r)
