@@ -114,7 +114,7 @@ def test_workspace_bytes_cover_the_matrix_core_streams():
     for n, p in [(200, 500), (1000, 50000), (1008, 16), (2016, 1000), (1, 1)]:
         nit = (p + 15) // 16 + 2
         tiles = (n + 15) // 16
-        rows = 16 * max(6 * -(-tiles // 6), 7 * -(-tiles // 7) if n <= 1008 else 0)
+        rows = 16 * max(6 * -(-tiles // 6), 7 * -(-tiles // 7) if n <= 1232 else 0)
         assert f(n, p) >= 8 * nit * rows * 32, (n, p)
     assert f(1000, 50000) > f(1000, 25000) > f(1000, 16)
     # n beyond the matrix-core kernel: only the step records remain
