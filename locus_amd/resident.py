@@ -77,7 +77,7 @@ class ResidentContext:
         return out
 
     def close(self):
-        if self._h is not None:
+        if getattr(self, "_h", None) is not None:     # also safe when __init__ raised
             _lib.lib().locus_hip_ctx_destroy(self._h)
             self._h = None
 
