@@ -47,6 +47,21 @@ def test_ctx_sweep_matches_oracle_routine(oracle, hip, variant, shape):
     assert e0 is not None and np.isfinite(e0)
 
 
+def test_ctx_sweep_as_core_probit_loop(oracle, hip):
+    """coreProbitLoop (src/coreLoop.cpp:139-171) through the context, as the header describes:
+    W in place of Y, tau_vb = 1, log_tau_vb = 0, the scalar sig2_beta_vb repeated."""
+    from locus_amd.resident import ResidentContext
+    n, p, d = 130, 45, 6
+    inp = inputs_for("probit", n, p, d, seed=9)
+    ref = call_variant(oracle, "probit", inp)
+    with ResidentContext(inp["X"], inp["Y"]) as ctx:              # inp["Y"] is W here
+        ctx.set_state(inp["gam_vb"], inp["mu_beta_vb"], inp["mat_z_mu"])
+        ctx.sweep(inp["log_om_vb"], inp["log_1_min_om_vb"], inp["log_sig2_inv_vb"], np.zeros(d),
+                  np.full(d, float(inp["sig2_beta_vb"])), np.ones(d), inp["shuffled_ind"])
+        got = ctx.get_state()
+    assert_parity(got, ref, what="ctx probit")
+
+
 def test_ctx_rejects_misuse(hip):
     from locus_amd._lib import LocusHipError
     from locus_amd.resident import ResidentContext
