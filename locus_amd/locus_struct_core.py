@@ -177,7 +177,9 @@ def locus_struct_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_v
         rng = np.random.default_rng(0)
         perm_fn = lambda it: rng.permutation(p).astype(np.float64)  # noqa: E731
 
-    blocks = StructBlocks(d, list_struct["vec_fac_st"], list_hyper["s02"], X)   # :30
+    # :30 -- on the GPU when there is one (the CPU test backend keeps the numpy path)
+    blocks = StructBlocks(d, list_struct["vec_fac_st"], list_hyper["s02"], X,
+                          device=device if device.type == "cuda" else None)
     hyper_loc = dict(list_hyper)
     for key in ("eta", "kappa"):
         hyper_loc[key] = np.broadcast_to(np.asarray(list_hyper[key], dtype=np.float64),

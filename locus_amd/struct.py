@@ -104,6 +104,50 @@ def near_pd_corr(x, eig_tol=1e-6, conv_tol=1e-7, posd_tol=1e-8, maxit=100):
     return X[0] if single else X
 
 
+def near_pd_corr_t(x, eig_tol=1e-6, conv_tol=1e-7, posd_tol=1e-8, maxit=100):
+    """near_pd_corr on a stack [nb, b, b] of torch tensors (any device): the same iteration with
+    batched torch.linalg.eigh -- 7 ms per pass over 500 blocks of 100 on MI355X against 0.3 s on
+    the host, which matters when blocks are rank-deficient (n < block size) and Higham's
+    projections need tens of passes."""
+    import torch
+    nb, b, _ = x.shape
+    X = x.clone()
+    DS = torch.zeros_like(X)
+    active = torch.ones(nb, dtype=torch.bool, device=x.device)
+    eye = torch.eye(b, dtype=torch.bool, device=x.device)
+
+    def eigh_desc(A):
+        w, Q = torch.linalg.eigh(A)
+        return w.flip(-1), Q.flip(-1)
+    for _ in range(maxit):
+        idx = active.nonzero().flatten()
+        if idx.numel() == 0:
+            break
+        Yk = X[idx]
+        Rk = Yk - DS[idx]
+        w, Q = eigh_desc(Rk)
+        keep = w > eig_tol * w[:, :1]
+        if not bool(keep.any(dim=1).all()):
+            raise ValueError("Matrix seems negative semi-definite")
+        wk = torch.where(keep, w, torch.zeros_like(w))
+        Xn = (Q * wk[:, None, :]) @ Q.transpose(1, 2)
+        DS[idx] = Xn - Rk
+        Xn[:, eye] = 1.0
+        conv = ((Yk - Xn).abs().sum(dim=2).amax(dim=1) / Yk.abs().sum(dim=2).amax(dim=1))
+        X[idx] = Xn
+        active[idx[conv <= conv_tol]] = False
+    w, Q = eigh_desc(X)                                   # do2eigen
+    floor = posd_tol * w[:, 0].abs()
+    for i in (w[:, -1] < floor).nonzero().flatten().tolist():
+        wi = torch.where(w[i] < floor[i], floor[i], w[i])
+        od = X[i].diagonal().clone()
+        Xi = Q[i] @ (wi[:, None] * Q[i].T)
+        dv = torch.sqrt(torch.maximum(floor[i], od) / Xi.diagonal())
+        X[i] = dv[:, None] * Xi * dv[None, :]
+    X[:, eye] = 1.0
+    return X
+
+
 def _cor(Xb):
     """cor() of the columns of Xb (n x b)."""
     Xc = Xb - Xb.mean(axis=0)
@@ -116,7 +160,9 @@ def _cor(Xb):
 class StructBlocks:
     """S0_inv, sig2_theta_vb and their log-determinants per block (R/update_vb.R:349-369)."""
 
-    def __init__(self, d, vec_fac_st, s02, X):
+    def __init__(self, d, vec_fac_st, s02, X, device=None):
+        """`device`: a torch GPU device runs the per-block correlation, nearPD, inverses and
+        log-determinants there (batched torch.linalg); None keeps them in numpy."""
         self.slices = block_slices(vec_fac_st)
         p = len(vec_fac_st)
         self.S0_inv = [None] * len(self.slices)
@@ -126,12 +172,15 @@ class StructBlocks:
         for i, (lo, hi) in enumerate(self.slices):
             by_size.setdefault(hi - lo, []).append(i)
         for b, ids in by_size.items():
-            C = np.stack([_cor(X[:, self.slices[i][0]:self.slices[i][1]]) for i in ids])
-            C = near_pd_corr(C)
-            S = np.linalg.inv(C) / s02                                     # :354
-            V = np.linalg.inv(S + d * np.eye(b)[None])                     # :360
-            sg1, ld1 = np.linalg.slogdet(S)                                # R/utils.R:164-176
-            sg2, ld2 = np.linalg.slogdet(V)
+            if device is not None:
+                S, V, sg1, ld1, sg2, ld2 = self._setup_on_device(X, ids, b, d, s02, device)
+            else:
+                C = np.stack([_cor(X[:, self.slices[i][0]:self.slices[i][1]]) for i in ids])
+                C = near_pd_corr(C)
+                S = np.linalg.inv(C) / s02                                     # :354
+                V = np.linalg.inv(S + d * np.eye(b)[None])                     # :360
+                sg1, ld1 = np.linalg.slogdet(S)                                # R/utils.R:164-176
+                sg2, ld2 = np.linalg.slogdet(V)
             for t, i in enumerate(ids):
                 self.S0_inv[i], self.sig2_theta[i] = S[t], V[t]
                 self.sum_log_det[i] = sg1[t] * ld1[t] + sg2[t] * ld2[t]    # :369
@@ -149,6 +198,25 @@ class StructBlocks:
         self.e_theta_const = float(np.sum(self.sum_log_det) - np.sum(self.trace_SV) + p) / 2
         self.sum_diag_sig2_theta = float(np.sum(self.diag_sig2_theta))
         self._S_m0 = (None, None)
+
+    def _setup_on_device(self, X, ids, b, d, s02, device):
+        """R/update_vb.R:349-369 for the blocks `ids` of size b, batched on the GPU."""
+        import torch
+        pos = np.array([self.slices[i][0] for i in ids])[:, None] + np.arange(b)[None, :]
+        Xd = X if torch.is_tensor(X) else torch.from_numpy(np.ascontiguousarray(X.T)).to(device).t()
+        Xb = Xd[:, torch.as_tensor(pos.reshape(-1), device=device)]
+        Xb = Xb.reshape(Xd.shape[0], len(ids), b).permute(1, 0, 2)           # [nb][n][b]
+        Xc = Xb - Xb.mean(dim=1, keepdim=True)
+        sd = torch.sqrt((Xc * Xc).sum(dim=1))
+        C = (Xc.transpose(1, 2) @ Xc) / (sd[:, :, None] * sd[:, None, :])     # cor()
+        C[:, torch.eye(b, dtype=torch.bool, device=device)] = 1.0
+        C = near_pd_corr_t(C.clamp(-1.0, 1.0))
+        S = torch.linalg.inv(C) / s02                                          # :354
+        V = torch.linalg.inv(S + d * torch.eye(b, dtype=S.dtype, device=device)[None])   # :360
+        sg1, ld1 = torch.linalg.slogdet(S)
+        sg2, ld2 = torch.linalg.slogdet(V)
+        h = lambda t: t.cpu().numpy()  # noqa: E731
+        return h(S), h(V), h(sg1), h(ld1), h(sg2), h(ld2)
 
     def update_theta_vb_(self, rs_W, m0):
         """R/update_vb.R:315-319: theta_bl = sig2_theta_bl (rowSums(W_bl) + S0_inv_bl m0_bl)."""
