@@ -470,3 +470,32 @@ def test_cross_validation_mix_on_gpu(oracle, hip):
     vb = locus(Yb, sim["X"], None, Z=Z, link="mix", ind_bin=ind_bin, list_cv=cv, user_seed=5,
                maxit=2, verbose=False)
     assert vb["p_star"] in cv["p0_av_grid"]
+
+
+@pytest.mark.parametrize("mode", ["identity", "z", "struct", "logit", "probit", "mix", "blocks"])
+def test_locus_every_mode_on_gpu(hip, mode):
+    """locus() end to end on the device for every link / option, with its default hyper-parameters
+    and (device-drawn) initial values: shapes, ranges, the removed columns and a finite ELBO."""
+    from locus_amd import locus, set_blocks, set_struct
+    from locus_amd.simulate import simulate
+    n, p, d = 120, 90, 8
+    link = mode if mode in ("logit", "probit") else "identity"
+    sim = simulate(n, p, d, 6, seed=12, link=link)
+    X = np.array(sim["X_raw"] if "X_raw" in sim else sim["X"], dtype=np.float64)
+    X = np.hstack([X, X[:, [3]], np.full((n, 1), 2.0)])       # one duplicated, one constant column
+    Y = sim["Y"].copy()
+    kw = dict(link=link, user_seed=3, maxit=4, verbose=False, full_output=True)
+    if mode == "z":
+        kw["Z"] = np.random.default_rng(1).normal(size=(n, 2))
+    if mode == "mix":
+        Y[:, [1, 4]] = (Y[:, [1, 4]] > 0).astype(np.float64)
+        kw.update(link="mix", ind_bin=[1, 4])
+    if mode == "struct":
+        kw["list_struct"] = set_struct(n, X.shape[1], np.arange(1, X.shape[1] + 1, 30))
+    if mode == "blocks":
+        kw["list_blocks"] = set_blocks(X.shape[1], [1, 31, 61])
+        kw.pop("full_output")
+    vb = locus(Y, X, 6, **kw)
+    assert list(vb["rmvd_x"]) == [p, p + 1]
+    assert vb["gam_vb"].shape == (p, d) and np.all((vb["gam_vb"] >= 0) & (vb["gam_vb"] <= 1))
+    assert np.all(np.isfinite(np.atleast_1d(vb["lb_opt"])))
