@@ -64,22 +64,38 @@ class IdentityHost(HostBase):
         self.rs_gam_t = self.a_t = self.b_t = None
         self._digam_sum, self._c_last = {}, 1.0
 
-    def _reduce_p(self, rs_gam_local, scalars):
+    def _reduce_p(self, rs_gam_local, scalars, omega=False):
         """ONE all-reduce of [rowSums(gam) (p) | scalars]; rowSums stays a tensor on its
-        device, the scalars (+ sum(rs_gam)) come back to the host."""
+        device, the scalars (+ sum(rs_gam)) come back to the host.  omega: the covariate-wise
+        ELBO terms (_omega_terms) are formed right away and ride in the same transfer, so that an
+        iteration costs one host synchronisation here instead of two."""
         import torch
         dev = rs_gam_local.device
         if self.a_t is None or self.a_t.device != dev:
             self.a_t = torch.from_numpy(self.a).to(dev)
             self.b_t = torch.from_numpy(self.b).to(dev)
             self._digam_sum = {}
+        if self.comm.world == 1:                       # nothing to exchange: no staging buffer
+            self.rs_gam_t = rs_gam_local.reshape(-1)
+            parts = [self.rs_gam_t.sum().reshape(1)]
+            if omega:
+                parts.append(self._omega_terms_t())
+            h = torch.cat(parts).cpu().numpy()
+            self.sum_gam = float(h[0])
+            self._omega_cache = (float(h[1]), float(h[2])) if omega else None
+            return np.asarray(scalars, dtype=np.float64).reshape(-1)
         tail = torch.as_tensor(np.asarray(scalars, dtype=np.float64).reshape(-1), device=dev)
         buf = torch.cat([rs_gam_local.reshape(-1), tail])
         self.comm.all_reduce_sum_(buf)
         self.rs_gam_t = buf[: self.p]
-        h = torch.cat([buf[self.p:], self.rs_gam_t.sum().reshape(1)]).cpu().numpy()
-        self.sum_gam = float(h[-1])
-        return h[:-1]
+        parts = [buf[self.p:], self.rs_gam_t.sum().reshape(1)]
+        if omega:
+            parts.append(self._omega_terms_t())
+        h = torch.cat(parts).cpu().numpy()
+        k = len(h) - (3 if omega else 1)
+        self.sum_gam = float(h[k])
+        self._omega_cache = (float(h[k + 1]), float(h[k + 2])) if omega else None
+        return h[:k]
 
     # length-p results for the caller (R/locus_core.R:242-252), on the host
     @property
@@ -119,6 +135,12 @@ class IdentityHost(HostBase):
         """Covariate-wise terms of the ELBO at c = 1 (R/locus_core.R:270-275; R/elbo.R:43-54,
         114-118), evaluated where rowSums(gam) lives; two scalars come back:
         sum_j rs_gam log om + (d - rs_gam) log(1 - om)  and  e_omega_."""
+        if getattr(self, "_omega_cache", None) is not None:     # came with the last reduction
+            return self._omega_cache
+        s_bg, e_om = self._omega_terms_t().cpu().numpy()
+        return float(s_bg), float(e_om)
+
+    def _omega_terms_t(self):
         import torch
         d = self.d
         rs, a, b = self.rs_gam_t, self.a_t, self.b_t
@@ -131,8 +153,7 @@ class IdentityHost(HostBase):
         s_bg = (rs * log_om_vb).sum() + ((d - rs) * log_1_min_om_vb).sum()
         e_om = ((a - a_vb) * log_om_vb + (b - b_vb) * log_1_min_om_vb - lbeta(a, b)
                 + lbeta(a_vb, b_vb)).sum()
-        s_bg, e_om = torch.stack([s_bg, e_om]).cpu().numpy()
-        return float(s_bg), float(e_om)
+        return torch.stack([s_bg, e_om])
 
     def _log_om_terms(self, c):
         """log_om_vb, log_1_min_om_vb (R/update_vb.R:187,190) on the device of rowSums(gam)."""
@@ -191,7 +212,7 @@ class IdentityHost(HostBase):
                        + E.e_beta_gamma_local_(cs_gam, cs_m2, ent_local, log_tau_vb, s2, si, tau)
                        + E.e_tau_(self.eta, eta_vb, self.kappa, kappa_vb, log_tau_vb, tau))
         import torch
-        sc = self._reduce_p(rs_gam_local, [t_loc, abc_loc])
+        sc = self._reduce_p(rs_gam_local, [t_loc, abc_loc], omega=with_elbo)
         self.sum_tau_m2 = float(sc[0])
         self._c_last = c
         if not with_elbo:

@@ -100,7 +100,8 @@ class MixHost(IdentityHost):
                + E.e_tau_(self.eta, eta_vb, self.kappa, kappa_vb, log_tau_vb[:dc], tau[:dc])
                + 0.5 * float(np.sum(-tau * m2a_z) + q * np.sum(log_tau_vb)
                              + np.sum(np.log(self.sig2_alpha_vb)) + self.m2_alpha.size))
-        sc = self._reduce_p(rs_gam_local, [float(tau @ cs_m2), loc] + list(self.m2_alpha @ tau))
+        sc = self._reduce_p(rs_gam_local, [float(tau @ cs_m2), loc] + list(self.m2_alpha @ tau),
+                            omega=True)
         self.sum_tau_m2 = float(sc[0])
         self.xi_sum = np.array(sc[2:2 + q])
         s_bg, e_om = self._omega_terms()

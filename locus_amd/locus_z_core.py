@@ -106,7 +106,7 @@ class ZHost(IdentityHost):
                    # e_alpha_ (R/elbo.R:11-19) without the log zeta2_inv term (replicated)
                    + 0.5 * float(np.sum(-tau * m2a_z) + q * np.sum(log_tau_vb)
                                  + np.sum(np.log(self.sig2_alpha_vb)) + self.m2_alpha.size))
-        sc = self._reduce_p(rs_gam_local, [t_loc, loc] + list(xi_loc))
+        sc = self._reduce_p(rs_gam_local, [t_loc, loc] + list(xi_loc), omega=with_elbo)
         self.sum_tau_m2 = float(sc[0])
         self.xi_sum = np.array(sc[2:2 + q])
         self._c_last = c
