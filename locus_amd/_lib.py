@@ -127,3 +127,10 @@ def check(code):
 
 def device_count():
     return lib().locus_hip_device_count()
+
+
+def sweep_config(n, d, logit=False):
+    """Kernel geometry (NPL, C, S, G) the library picks for n rows and d resident responses."""
+    cfg = (ctypes.c_int32 * 4)()
+    check(lib().locus_hip_sweep_config(int(n), int(d), 1 if logit else 0, cfg))
+    return tuple(int(c) for c in cfg)

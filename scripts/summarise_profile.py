@@ -35,13 +35,13 @@ if seq:
                         hbm_bytes_per_launch=rd + wr, hbm_read_bytes=rd, hbm_write_bytes=wr,
                         correction="2 x FETCH_SIZE (gfx950, 16-B coalesced loads) + WRITE_SIZE, "
                                    "summed over the kernels of one sweep"))
-for k in []:
+for k in sorted(fetch, key=lambda k: -sum(fetch[k])):      # one row per kernel, largest reader first
     fs = sum(fetch[k]) / len(fetch[k])
     ws = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
     lines.append(f"\"{k[:80]}\",{len(fetch[k])},{fs:.1f},{ws:.1f},{2*fs*1024:.4e},{ws*1024:.4e}")
     if "sweep_kernel" in k:
-        traffic.append(dict(n=n, p=p, d_loc=d_loc, kernel=k,
-                            hbm_bytes_per_launch=2 * fs * 1024 + ws * 1024,
+        traffic.append(dict(n=n, p=p, d_loc=d_loc, kernel=k, per="dispatch of this kernel",
+                            hbm_bytes_per_dispatch=2 * fs * 1024 + ws * 1024,
                             fetch_size_kib=fs, write_size_kib=ws,
                             correction="2 x FETCH_SIZE (gfx950, 16-B coalesced loads) + WRITE_SIZE"))
 open(f"profiles/{tag}_bench_hbm_counters.csv", "w").write("\n".join(lines) + "\n")
