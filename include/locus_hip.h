@@ -281,6 +281,9 @@ int locus_hip_bin_rows_dev(const double* state, const double* s2jk, double s2c, 
  *     ctx_create(X, Y)                               once   (X, Y as passed to coreLoop)
  *     ctx_set_state(gam_vb, mu_beta_vb, mat_z_mu)    once   (R/locus_core.R:36-42)
  *     per iteration: the R updates of the length-p / length-d quantities, then
+ *       [ctx_set_response(W, mat_z_mu)  coreZLoop / coreProbitLoop / mix drivers only: the new
+ *                         alpha_vb's Z alpha_vb and / or the new latent W, R/locus_z_core.R:100-107,
+ *                         R/locus_probit_core.R:76-88]
  *       ctx_sweep(...)  = coreLoop (R/locus_core.R:90-95) + rowSums(gam_vb) + the column sums
  *                         update_eta/kappa/lambda/nu_vb_ and elbo_ need (R/update_vb.R:198-237)
  *     ctx_get_state(...)                              once, at the end
@@ -293,11 +296,23 @@ typedef struct locus_hip_ctx locus_hip_ctx;
 int locus_hip_ctx_create(const double* X, const double* Y, int64_t n, int64_t p, int64_t d,
                          locus_hip_ctx** ctx);
 
-/* gam_vb, mu_beta_vb p x d column-major; forms beta_vb = gam_vb * mu_beta_vb and
- * mat_x_m1 = X beta_vb (R/locus_core.R:36-40).  mat_z_mu (n x d) or NULL: the term coreZLoop /
- * coreProbitLoop subtract (src/coreLoop.cpp:80); pass it again whenever alpha_vb changed. */
+/* (Re)starts the fit from gam_vb, mu_beta_vb (p x d column-major): uploads them over the
+ * resident planes, forms beta_vb = gam_vb * mu_beta_vb and mat_x_m1 = X beta_vb
+ * (R/locus_core.R:36-40).  mat_z_mu (n x d) or NULL: the term coreZLoop / coreProbitLoop subtract
+ * (src/coreLoop.cpp:80).  Call it ONCE, before the loop; it is NOT the way to tell the context
+ * about a new alpha_vb or W between iterations (it would reset the fit to the host's stale
+ * gam_vb / mu_beta_vb): that is locus_hip_ctx_set_response. */
 int locus_hip_ctx_set_state(locus_hip_ctx* ctx, const double* gam_vb, const double* mu_beta_vb,
                             const double* mat_z_mu);
+
+/* Between iterations of locus_z_core_ / locus_probit_core_ / locus_mix_core_: replaces the
+ * response matrix the sweep sees (Y_or_W: n x d, the probit / mix latent W of
+ * R/update_vb.R:382-386; NULL = unchanged) and / or mat_z_mu = Z alpha_vb (n x d,
+ * R/locus_z_core.R:100-107; NULL = unchanged) and rebuilds the residual on the device from the
+ * resident mat_x_m1.  gam_vb, mu_beta_vb, beta_vb and mat_x_m1 keep their resident values.
+ * No counterpart in the reference, where coreZLoop reads Y and mat_z_mu in place each call
+ * (src/coreLoop.cpp:60-62,84). */
+int locus_hip_ctx_set_response(locus_hip_ctx* ctx, const double* Y_or_W, const double* mat_z_mu);
 
 /* One sweep with the arguments of coreLoop (probit: tau_vb = 1, log_tau_vb = 0, sig2_beta_vb
  * repeated; struct: log Phi / log(1 - Phi) in place of log_om / log_1_min_om, c = 1).  Outputs,

@@ -87,6 +87,7 @@ SIGNATURES = {
     # resident context (host pointers)
     "locus_hip_ctx_create": (_int, [_ptr, _ptr, _i64, _i64, _i64, ctypes.POINTER(_ptr)]),
     "locus_hip_ctx_set_state": (_int, [_ptr, _ptr, _ptr, _ptr]),
+    "locus_hip_ctx_set_response": (_int, [_ptr, _ptr, _ptr]),
     "locus_hip_ctx_sweep": (_int, [_ptr, _ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr, _dbl, _dbl,
                                    _ptr, _ptr, ctypes.POINTER(_dbl)]),
     "locus_hip_ctx_stats": (_int, [_ptr, _ptr, _dbl, _ptr, _ptr, ctypes.POINTER(_dbl)]),

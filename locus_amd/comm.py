@@ -48,6 +48,30 @@ class DistComm(Comm):
     def barrier(self):
         self._dist.barrier(group=self.group)
 
+    def all_gather_columns(self, local, d):
+        """rows x d_r column shards of every rank -> the rows x d matrix (Fortran order) on every
+        rank.  Shards may differ in width by one column (shard()), so each rank's piece travels
+        as a [d_r][rows] block padded to the widest shard; the pad is dropped on arrival."""
+        import numpy as np
+        dist = self._dist
+        rows = local.shape[0]
+        bounds = [shard_bounds(d, r, self.world) for r in range(self.world)]
+        wmax = max(hi - lo for lo, hi in bounds)
+        lo, hi = bounds[self.rank]
+        assert local.shape[1] == hi - lo
+        mine = torch.zeros((wmax, rows), dtype=torch.float64)
+        mine[: hi - lo] = torch.from_numpy(np.ascontiguousarray(local.T))
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        if on_gpu:
+            mine = mine.cuda()
+        out = torch.empty((self.world * wmax, rows), dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        out = out.cpu().numpy().reshape(self.world, wmax, rows)
+        full = np.empty((rows, d), order="F")
+        for r, (a, b) in enumerate(bounds):
+            full[:, a:b] = out[r, : b - a].T
+        return full
+
 
 def shard_bounds(d, rank, world):
     return (d * rank) // world, (d * (rank + 1)) // world

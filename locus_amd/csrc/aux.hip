@@ -1,5 +1,7 @@
 // Small bandwidth-bound helper kernels around the sweep (layout changes, the
 // per-sweep prologue, the gamma reductions that update_vb.R / elbo.R need).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 #include "fastmath.h"
@@ -133,10 +135,10 @@ int residual_transform(const double* Y, const double* A, const double* Zmu, cons
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ in,
                                                         double* __restrict__ out, int rows,
-                                                        int cols)
+                                                        int cols, int by0)
 {
     __shared__ double tile[32][33];
-    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int bx = blockIdx.x * 32, by = (by0 + blockIdx.y) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int i = ty; i < 32; i += 8) {
         const int r = by + i, c = bx + tx;
@@ -151,9 +153,13 @@ __global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict
 
 int transpose(const double* in, double* out, int rows, int cols, hipStream_t st)
 {
-    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, in, out, rows, cols);
-    LOCUS_HIP_CHECK(hipGetLastError());
+    // grid.y is limited to 65535 blocks: more than 2 097 120 input rows go in several launches
+    const int tiles_y = (rows + 31) / 32;
+    for (int by0 = 0; by0 < tiles_y; by0 += 65535) {
+        dim3 grid((cols + 31) / 32, std::min(65535, tiles_y - by0));
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, in, out, rows, cols, by0);
+        LOCUS_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 

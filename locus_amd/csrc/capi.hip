@@ -19,9 +19,11 @@ namespace {
 // RAII device allocation for the stateless entry points.
 struct DevMem {
     void* p = nullptr;
-    ~DevMem()
+    ~DevMem() { release(); }
+    void release()
     {
         if (p) (void)hipFree(p);
+        p = nullptr;
     }
     int alloc(size_t bytes)
     {
@@ -48,7 +50,8 @@ int download(double* host, const DevMem& m, size_t count)
 int check_dims(int64_t n, int64_t p, int64_t d)
 {
     LOCUS_REQUIRE(n >= 1 && p >= 1 && d >= 1, "n, p and d must be >= 1");
-    LOCUS_REQUIRE(p < (1ll << 31) && d < (1ll << 31) && n * d < (1ll << 40) && p * d < (1ll << 40),
+    LOCUS_REQUIRE(n < (1ll << 31) && p < (1ll << 31) && d < (1ll << 31) && n * d < (1ll << 40) &&
+                      p * d < (1ll << 40),
                   "problem too large");
     return 0;
 }
@@ -230,12 +233,17 @@ int run_loop(int kind, const double* X, const double* Y, double* gam, const doub
 
     DevMem dX, dXp, dxtx, dY, dA, dZ, dW2, dR, dstate, dtmp, dlo, dl1, dind, dscale, dhinv, dcst,
         ds2k, ds2, dls2, dxwx, dws;
-    // X: raw copy -> packed; the raw copy is released before the big state buffers
+    // X: raw copy -> packed; the raw copy is released before the big state buffers are
+    // allocated (logit keeps it: the X^2 contraction below reads it)
     {
         if ((rc = upload(dX, X, np))) return rc;
         if ((rc = dXp.alloc(sizeof(double) * (size_t)p * ld))) return rc;
         if ((rc = dxtx.alloc(sizeof(double) * (size_t)p))) return rc;
         if ((rc = pack_x(dX.d(), dXp.d(), dxtx.d(), (int)n, (int)p, (int)ld, st))) return rc;
+        if (kind != 2) {
+            LOCUS_HIP_CHECK(hipStreamSynchronize(st));
+            dX.release();
+        }
     }
     if ((rc = upload(dY, Y, nd))) return rc;
     if ((rc = upload(dA, M, nd))) return rc;
@@ -565,22 +573,22 @@ int locus_hip_transpose_dev(const double* in, double* out, int64_t rows, int64_t
 {
     LOCUS_REQUIRE(in && out && rows >= 1 && cols >= 1 && rows < (1ll << 31) && cols < (1ll << 31),
                   "transpose: bad arguments");
-    LOCUS_REQUIRE((rows + 31) / 32 <= 65535, "transpose: too many rows (grid.y)");
     return transpose(in, out, (int)rows, (int)cols, (hipStream_t)stream);
 }
 
 int locus_hip_gamma_rows_dev(const double* gam, double* rs_gam, double* ent, int64_t p, int64_t d,
                              double eps, void* stream)
 {
-    LOCUS_REQUIRE(gam && rs_gam && p >= 1 && d >= 1, "gamma_rows: bad arguments");
+    LOCUS_REQUIRE(gam && rs_gam && p >= 1 && d >= 1 && p < (1ll << 31) && d < (1ll << 31),
+                  "gamma_rows: bad arguments");
     return gamma_rows(gam, rs_gam, ent, (int)p, (int)d, eps, (hipStream_t)stream);
 }
 
 int locus_hip_state_cols_dev(double* state, const double* s2k, const double* s2jk,
                              double* st_partial, int64_t p, int64_t d, int64_t nchunks, void* stream)
 {
-    LOCUS_REQUIRE(state && st_partial && (s2k || s2jk) && p >= 1 && d >= 1 && nchunks >= 1 &&
-                      nchunks <= 65535,
+    LOCUS_REQUIRE(state && st_partial && (s2k || s2jk) && p >= 1 && d >= 1 && p < (1ll << 31) &&
+                      d < (1ll << 31) && nchunks >= 1 && nchunks <= 65535,
                   "state_cols: bad arguments");
     return state_cols(state, s2k, s2jk, st_partial, (int)p, (int)d, (int)nchunks,
                       (hipStream_t)stream);
@@ -607,7 +615,8 @@ int locus_hip_batch_update_dev(double* state, const double* lo, const double* l1
                                const double* hinv, const double* cstk, double log_sig2_inv,
                                double nm1, int probit, int64_t p, int64_t d, void* stream)
 {
-    LOCUS_REQUIRE(state && lo && l1 && fac && hinv && cstk && p >= 1 && d >= 1,
+    LOCUS_REQUIRE(state && lo && l1 && fac && hinv && cstk && p >= 1 && d >= 1 && p < (1ll << 31) &&
+                      d < (1ll << 31),
                   "batch_update: bad arguments");
     return batch_update(state, lo, l1, fac, hinv, cstk, log_sig2_inv, nm1, probit, (int)p, (int)d,
                         (hipStream_t)stream);
@@ -618,7 +627,8 @@ int locus_hip_batch_update_dev(double* state, const double* lo, const double* l1
 int locus_hip_m2_minus_b2_dev(const double* state, const double* s2jk, double s2c, double* D,
                               int64_t p, int64_t d, void* stream)
 {
-    LOCUS_REQUIRE(state && D && p >= 1 && d >= 1, "m2_minus_b2: bad arguments");
+    LOCUS_REQUIRE(state && D && p >= 1 && d >= 1 && p < (1ll << 31) && d < (1ll << 31),
+                  "m2_minus_b2: bad arguments");
     return m2_minus_b2(state, s2jk, s2c, D, (size_t)p * d, (hipStream_t)stream);
 }
 

@@ -150,6 +150,32 @@ int locus_hip_ctx_set_state(locus_hip_ctx* c, const double* gam_vb, const double
     return 0;
 }
 
+int locus_hip_ctx_set_response(locus_hip_ctx* c, const double* Y_or_W, const double* mat_z_mu)
+{
+    int rc = enter(c);
+    if (rc) return rc;
+    LOCUS_REQUIRE(c->has_state, "ctx_set_response: call locus_hip_ctx_set_state first");
+    LOCUS_REQUIRE(Y_or_W || mat_z_mu, "ctx_set_response: nothing to replace (both pointers NULL)");
+    const size_t nd = (size_t)c->n * c->d;
+    // mat_x_m1 = Y_old - R - Zmu_old is what the sweeps have built; it does not change here
+    if ((rc = residual_transform(c->Y, c->R, c->has_zmu ? c->Zmu : nullptr, nullptr, c->M, nd, 0,
+                                 nullptr)))
+        return rc;
+    LOCUS_HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (Y_or_W) LOCUS_HIP_CHECK(hipMemcpy(c->Y, Y_or_W, sizeof(double) * nd, hipMemcpyHostToDevice));
+    if (mat_z_mu) {
+        if (!c->Zmu && (rc = dev_alloc(&c->Zmu, nd))) return rc;
+        LOCUS_HIP_CHECK(hipMemcpy(c->Zmu, mat_z_mu, sizeof(double) * nd, hipMemcpyHostToDevice));
+        c->has_zmu = true;
+    }
+    // R = Y_new - mat_x_m1 - Zmu_new
+    if ((rc = residual_transform(c->Y, c->M, c->has_zmu ? c->Zmu : nullptr, nullptr, c->R, nd, 1,
+                                 nullptr)))
+        return rc;
+    LOCUS_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
 int locus_hip_ctx_sweep(locus_hip_ctx* c, const double* log_om_vb, const double* log_1_min_om_vb,
                         double log_sig2_inv_vb, const double* log_tau_vb,
                         const double* sig2_beta_vb, const double* tau_vb,

@@ -10,7 +10,10 @@ namespace locus {
 // instruction costs 8 issue cycles, so the instruction COUNT of the chain is what matters.
 __device__ __forceinline__ double exp_nonpos(double x)
 {
-    x = fmax(x, -800.0);  // exp underflows to 0 below -745.2; keeps k in int range
+    // exp underflows to 0 below -745.2; the clamp keeps k in int range.  Written as a select, not
+    // fmax: fmax(NaN, -800) = -800 would turn a NaN log-odds into gam = 1, whereas the reference
+    // propagates it (std::exp in src/utils.cpp:3-12); with the select a NaN stays a NaN.
+    x = (x < -800.0) ? -800.0 : x;
     const double k = __builtin_rint(x * 1.4426950408889634074);
     double r = fma(k, -6.93147180369123816490e-01, x);
     r = fma(k, -1.90821492927058770002e-10, r);

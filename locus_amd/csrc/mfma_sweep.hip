@@ -127,7 +127,7 @@ size_t mfma_lds_bytes(int T)
     return sizeof(double) * (2 * (size_t)(mfma_waves(T) + 1) * T * 256 + 2 * 16 * 64 + 2 * 16 * 64 + 2 * 256 + 2 * 64 + 8);
 }
 
-static int device_cus()
+int device_cus()
 {
     // LOCUS_HIP_MFMA_CUS overrides the CU count the launch plan assumes (tests: forces the
     // multi-launch plan at small d)

@@ -100,7 +100,7 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
         }
     }
     const int units = (n + 63) / 64;  // 64-row units a column needs
-    const int num_cu = 256;
+    const int num_cu = device_cus();
     double best = 1e300;
     SweepConfig bc{0, 0, 0, 0};
     for (int npl : {2, 4, 8, 16}) {

@@ -299,6 +299,9 @@ def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
     if perm_fn is None:
         rng = np.random.default_rng(0)
         perm_fn = lambda it: rng.permutation(p).astype(np.float64)  # noqa: E731
+    if alpha_perm_fn is None:     # R: sample(1:q) every iteration (R/locus_logistic_core.R:79,
+        rng_a = np.random.default_rng(1)   # R/locus_probit_core.R:76); same stream on every rank
+        alpha_perm_fn = lambda it: rng_a.permutation(q)  # noqa: E731
     host = BinHost(n, p, d, q, list_hyper, comm)
     px = dv.PackedX(dv.to_device_colmajor(X, device))
     Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
@@ -320,8 +323,8 @@ def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
         it += 1
         if verbose and (it == 1 or it % 5 == 0):
             print(f"Iteration {it}... ")
-        order = None if alpha_perm_fn is None else alpha_perm_fn(it)
-        lb_new = eng.iterate(np.ascontiguousarray(perm_fn(it), dtype=np.float64), order)
+        lb_new = eng.iterate(np.ascontiguousarray(perm_fn(it), dtype=np.float64),
+                             alpha_perm_fn(it))
         if trace is not None:
             trace.append((it, lb_new))
         if verbose and (it == 1 or it % 5 == 0):

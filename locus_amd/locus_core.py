@@ -319,12 +319,13 @@ def resolve_backend(test_backend, device):
     return dv, device or torch.device("cuda", torch.cuda.current_device())
 
 
-def checkpoint_(it, checkpoint_path, gam_vb_fn, converged, lb_new, lb_old, om_vb, rate=100):
-    """R/utils.R:316-336 (npz instead of RData): every `rate` iterations, keep the last two."""
+def checkpoint_(it, checkpoint_path, gam_vb_fn, converged, lb_new, lb_old, om_vb_fn, rate=100):
+    """R/utils.R:316-336 (npz instead of RData): every `rate` iterations, keep the last two.
+    gam_vb_fn / om_vb_fn are called only when a file is written (both download from the GPU)."""
     if checkpoint_path is not None and it % rate == 0:
         np.savez(os.path.join(checkpoint_path, f"tmp_output_it_{it}.npz"), gam_vb=gam_vb_fn(),
                  converged=converged, it=it, lb_new=lb_new, diff_lb=abs(lb_new - lb_old),
-                 om_vb=om_vb)
+                 om_vb=om_vb_fn())
         old = os.path.join(checkpoint_path, f"tmp_output_it_{it - 2 * rate}.npz")
         if os.path.exists(old):
             os.remove(old)
@@ -416,7 +417,7 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
                 raise RuntimeError("ELBO not increasing monotonically. Exit. ")
             converged = abs(lb_new - lb_old) < tol                       # :205
             checkpoint_(it, checkpoint_path, lambda: _gather(comm, eng.download()["gam_vb"], d),
-                        converged, lb_new, lb_old, host.om_vb)
+                        converged, lb_new, lb_old, lambda: host.om_vb)
     checkpoint_clean_up_(checkpoint_path)
     if verbose and not converged:
         print("Maximal number of iterations reached before convergence. Exit.")
@@ -438,20 +439,12 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
 
 
 def _gather(comm, local, d):
-    """Concatenate the response shards (columns) of every rank, on every rank."""
+    """Concatenate the response shards (columns) of every rank, on every rank: ONE all-gather of
+    the shards themselves (rank r contributes rows x d_r doubles; nothing is zero-padded or
+    summed)."""
     if comm.world == 1:
         return local
-    import torch
-    import torch.distributed as dist
-    rows = local.shape[0]
-    full = np.zeros((rows, d), order="F")
-    k_lo, k_hi = comm.shard(d)
-    full[:, k_lo:k_hi] = local
-    t = torch.from_numpy(np.ascontiguousarray(full.T))
-    if dist.get_backend(comm.group) == "nccl":
-        t = t.cuda()
-    comm.all_reduce_sum_(t)
-    return np.asfortranarray(t.cpu().numpy().T)
+    return comm.all_gather_columns(np.asarray(local, dtype=np.float64), d)
 
 
 def _gather_vec(comm, local, d):

@@ -44,6 +44,16 @@ class ResidentContext:
         z = None if mat_z_mu is None else _f(mat_z_mu)
         _lib.check(_lib.lib().locus_hip_ctx_set_state(self._h, _p(g), _p(m), _p(z)))
 
+    def set_response(self, Y_or_W=None, mat_z_mu=None):
+        """New latent W and / or Z alpha_vb between iterations (coreZLoop / coreProbitLoop
+        drivers); the resident gam_vb / mu_beta_vb / mat_x_m1 are kept."""
+        y = None if Y_or_W is None else _f(Y_or_W)
+        z = None if mat_z_mu is None else _f(mat_z_mu)
+        for a in (y, z):
+            if a is not None and a.shape != (self.n, self.d):
+                raise ValueError("Y_or_W and mat_z_mu must be n x d")
+        _lib.check(_lib.lib().locus_hip_ctx_set_response(self._h, _p(y), _p(z)))
+
     def _outs(self, ent):
         return (np.empty(self.p), np.empty((4, self.d)), ctypes.c_double(0.0) if ent else None)
 

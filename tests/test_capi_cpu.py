@@ -119,3 +119,54 @@ def test_workspace_bytes_cover_the_matrix_core_streams():
     assert f(1000, 50000) > f(1000, 25000) > f(1000, 16)
     # n beyond the matrix-core kernel: only the step records remain
     assert f(4000, 50000) < 64 * 50000
+
+
+def _top_level_args(text, start):
+    """Number of top-level comma-separated arguments of the call whose '(' is at text[start]."""
+    depth, n_args, i, seen = 0, 1, start, False
+    while True:
+        ch = text[i]
+        if ch == "(":
+            depth += 1
+        elif ch == ")":
+            depth -= 1
+            if depth == 0:
+                return n_args if seen else 0
+        elif ch == "," and depth == 1:
+            n_args += 1
+        elif depth >= 1 and not ch.isspace():
+            seen = True
+        i += 1
+
+
+def test_rcpp_glue_calls_match_the_header():
+    """integration/rcpp/*.cpp cannot be compiled here (no R / Rcpp in the image): at least every
+    locus_hip_* call in it must name a declared entry point and pass as many arguments as the
+    header declares, and all eight .Call routines of the reference (src/RcppExports.cpp:191-201)
+    must be there."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "locus_hip.h")).read(),
+                 flags=re.S)
+    hdr = re.sub(r"\(\s*void\s*\)", "()", hdr)
+    arity = {m.group(1): _top_level_args(hdr, m.end() - 1)
+             for m in re.finditer(r"\b(locus_hip_[a-z0-9_]+)\s*\(", hdr)}
+    glue_dir = os.path.join(ROOT, "integration", "rcpp")
+    exported, called = set(), set()
+    for f in sorted(os.listdir(glue_dir)):
+        if not f.endswith((".cpp", ".h")):
+            continue
+        src = re.sub(r"//[^\n]*", "", open(os.path.join(glue_dir, f)).read())
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        exported |= set(re.findall(r"^(?:void|SEXP|Rcpp::List)\s+(\w+)\(", src, flags=re.M))
+        for m in re.finditer(r"\b(locus_hip_[a-z0-9_]+)\s*\(", src):
+            name = m.group(1)
+            if name in ("locus_hip_check",):
+                continue
+            assert name in arity, f"{f}: {name} is not declared in include/locus_hip.h"
+            assert _top_level_args(src, m.end() - 1) == arity[name], f"{f}: arity of {name}"
+            called.add(name)
+    for r_name in ("coreBatch", "coreZBatch", "coreProbitBatch", "coreLoop", "coreZLoop",
+                   "coreLogitLoop", "coreProbitLoop", "coreStructLoop"):
+        assert r_name in exported, r_name
+    stateless = {n for n in arity if n.startswith("locus_hip_core_")}
+    assert stateless <= called and len(stateless) == 8
+    assert {n for n in arity if n.startswith("locus_hip_ctx_")} <= called

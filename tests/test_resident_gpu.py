@@ -62,6 +62,44 @@ def test_ctx_sweep_as_core_probit_loop(oracle, hip):
     assert_parity(got, ref, what="ctx probit")
 
 
+@pytest.mark.parametrize("variant", ["z", "probit"])
+def test_ctx_several_iterations_with_changing_response(oracle, hip, variant):
+    """coreZLoop / coreProbitLoop through the context for several iterations, with mat_z_mu (and
+    for probit the latent W) changing between them as in R/locus_z_core.R:100-111 and
+    R/locus_probit_core.R:76-91: locus_hip_ctx_set_response must keep the resident gam_vb /
+    mu_beta_vb / mat_x_m1 (ctx_set_state would reset them to the host's stale copies)."""
+    from locus_amd.resident import ResidentContext
+    n, p, d = 140, 50, 9
+    inp = inputs_for(variant, n, p, d, seed=31)
+    rng = np.random.default_rng(5)
+    cur = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    with ResidentContext(inp["X"], inp["Y"]) as ctx:
+        ctx.set_state(inp["gam_vb"], inp["mu_beta_vb"], inp["mat_z_mu"])
+        for it in range(4):
+            if it:       # what the alpha loop / update_W_probit_ do between sweeps
+                cur["mat_z_mu"] = np.asfortranarray(
+                    cur["mat_z_mu"] + rng.normal(scale=0.05, size=(n, d)))
+                if variant == "probit":
+                    cur["Y"] = np.asfortranarray(cur["Y"] + rng.normal(scale=0.1, size=(n, d)))
+                    ctx.set_response(cur["Y"], cur["mat_z_mu"])
+                else:
+                    ctx.set_response(None, cur["mat_z_mu"])
+            cur["shuffled_ind"] = rng.permutation(p).astype(np.float64)
+            ref = call_variant(oracle, variant, cur)
+            if variant == "probit":
+                ctx.sweep(cur["log_om_vb"], cur["log_1_min_om_vb"], cur["log_sig2_inv_vb"],
+                          np.zeros(d), np.full(d, float(cur["sig2_beta_vb"])), np.ones(d),
+                          cur["shuffled_ind"])
+            else:
+                ctx.sweep(cur["log_om_vb"], cur["log_1_min_om_vb"], cur["log_sig2_inv_vb"],
+                          cur["log_tau_vb"], cur["sig2_beta_vb"], cur["tau_vb"],
+                          cur["shuffled_ind"], cur.get("c", 1.0))
+            got = ctx.get_state()
+            assert_parity(got, ref, rtol=1e-9, atol=1e-12, what=f"ctx {variant} iteration {it + 1}")
+            cur.update(ref)           # the oracle continues from its own output, the context from its
+    assert not np.array_equal(got["gam_vb"], inp["gam_vb"])
+
+
 def test_ctx_rejects_misuse(hip):
     from locus_amd._lib import LocusHipError
     from locus_amd.resident import ResidentContext
@@ -78,6 +116,8 @@ def test_ctx_rejects_misuse(hip):
         assert ei.value.code == -3
         np.testing.assert_array_equal(ctx.get_state(("gam_vb",))["gam_vb"], inp["gam_vb"])
         ctx.sweep(*args, inp["shuffled_ind"])                    # still usable afterwards
+        with pytest.raises(LocusHipError):                       # nothing to replace
+            ctx.set_response(None, None)
         with pytest.raises(ValueError):
             ctx.set_state(inp["gam_vb"][:, :2], inp["mu_beta_vb"][:, :2])
 
