@@ -166,8 +166,26 @@ typedef struct locus_hip_sweep_args {
 int locus_hip_sweep_dev(const locus_hip_sweep_args* args, int logit, void* stream);
 
 /* Synchronises `stream` and returns 0, or LOCUS_HIP_EPERM if the last sweep that used
- * `workspace` (sized for p covariates) was given an invalid shuffled_ind. */
+ * `workspace` (sized for p covariates) was given an invalid shuffled_ind.  workspace == NULL:
+ * the static workspace of the current device (the last locus_hip_sweep_static_dev there). */
 int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream);
+
+/* locus_hip_sweep_dev for callers that cannot allocate and have no workspace to lend: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE
+ * REFERENCE (which has no device); same arguments and results as locus_hip_sweep_dev, but
+ * args->workspace / workspace_bytes are ignored: step records, the permutation check and the
+ * block-packed operand copies go to a fixed array of LOCUS_HIP_STATIC_WORKSPACE_BYTES that is
+ * part of the library's code object (each GPU the library runs on holds it for the life of the
+ * process).  Calls no hipMalloc / hipFree or allocating routine.  Limits: returns
+ * LOCUS_HIP_EUNSUPPORTED when locus_hip_sweep_workspace_bytes(n, p) exceeds the array (n = 1000:
+ * p <= ~3900 for the identity family, whose matrix-core kernel packs X per sweep; logit and
+ * n > 2016 need ~28 p bytes: p up to ~2.3 million).  All calls on one GPU share that GPU's array:
+ * two such sweeps that overlap on one GPU (different streams or threads) race -- serialise them.
+ * Set-up: the first use on a device looks the array's address up (hipGetSymbolAddress; the HIP
+ * runtime may materialise the array at that moment).  A caller that must not trigger even that
+ * inside its hot region calls locus_hip_sweep_status_dev(NULL, 1, stream) once per device first. */
+#define LOCUS_HIP_STATIC_WORKSPACE_BYTES (64ll << 20)
+int locus_hip_sweep_static_dev(const locus_hip_sweep_args* args, int logit, void* stream);
 
 /* Geometry the library would pick for (n, d): fills cfg[4] = NPL, C, S, G
  * ({-1, 0, 0, 0}: the matrix-core sweep, launches planned from d; {-2, 0, 0, 0}: the

@@ -66,6 +66,7 @@ SIGNATURES = {
     "locus_hip_sweep_workspace_bytes": (_i64, [_i64, _i64]),
     "locus_hip_sweep_dev": (_int, [ctypes.POINTER(SweepArgs), _int, _ptr]),
     "locus_hip_sweep_status_dev": (_int, [_ptr, _i64, _ptr]),
+    "locus_hip_sweep_static_dev": (_int, [ctypes.POINTER(SweepArgs), _int, _ptr]),
     "locus_hip_sweep_config": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int32)]),
     "locus_hip_residual_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _ptr]),
     "locus_hip_transpose_dev": (_int, [_ptr, _ptr, _i64, _i64, _ptr]),

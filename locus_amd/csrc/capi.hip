@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/locus_hip.h"
@@ -116,6 +117,35 @@ WsView carve(void* ws, int64_t p)
     v.err = reinterpret_cast<int*>(c + b);
     v.xb = c + b + 256;
     return v;
+}
+
+// ---- scratch of the entry point that allocates nothing (locus_hip_sweep_static_dev) ----------
+// One array per GPU, part of the code object: every device the library runs on holds these
+// 64 MiB from the moment the library is loaded until the process ends.  In host code the NAME
+// `scratch` is only a handle for hipGetSymbolAddress; the device address differs per GPU and is
+// looked up once per device (static_scratch_ptr), and only that pointer is ever handed to
+// kernels, memsets and copies.
+static __device__ __align__(256) unsigned char scratch[LOCUS_HIP_STATIC_WORKSPACE_BYTES];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+// Device address of `scratch` on the CURRENT device (looked up on the first call per device).
+int static_scratch_ptr(void** out)
+{
+    int dev = -1;
+    LOCUS_HIP_CHECK(hipGetDevice(&dev));
+    LOCUS_REQUIRE(dev >= 0 && dev < kMaxDevices, "static workspace: device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* ptr = nullptr;
+        LOCUS_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        LOCUS_REQUIRE(ptr != nullptr, "static workspace: hipGetSymbolAddress returned NULL");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
 }
 
 int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
@@ -536,9 +566,39 @@ int locus_hip_sweep_dev(const locus_hip_sweep_args* args, int logit, void* strea
     return sweep_dev(args, logit, (hipStream_t)stream);
 }
 
+int locus_hip_sweep_static_dev(const locus_hip_sweep_args* args, int logit, void* stream)
+{
+    LOCUS_REQUIRE(args != nullptr, "args is NULL");
+    int rc = check_dims(args->n, args->p, args->d);
+    if (rc) return rc;
+    const size_t need = workspace_bytes(args->n, args->p);
+    if (need > (size_t)LOCUS_HIP_STATIC_WORKSPACE_BYTES) {
+        set_error("sweep_static: a sweep over p = " + std::to_string(args->p) + " covariates of n = " +
+                  std::to_string(args->n) + " rows needs " + std::to_string(need) +
+                  " bytes of scratch, the static workspace holds " +
+                  std::to_string((size_t)LOCUS_HIP_STATIC_WORKSPACE_BYTES) +
+                  " (use locus_hip_sweep_dev with a caller-owned workspace)");
+        return LOCUS_HIP_EUNSUPPORTED;
+    }
+    void* ptr = nullptr;
+    if ((rc = static_scratch_ptr(&ptr))) return rc;
+    locus_hip_sweep_args a = *args;
+    a.workspace = ptr;  // the device address, never the symbol's name
+    a.workspace_bytes = (int64_t)LOCUS_HIP_STATIC_WORKSPACE_BYTES;
+    // everything a sweep expects to start from zero (visited[], the error word) is cleared by
+    // build_steps through `ptr` on `stream`; the rest of the scratch is written before it is read
+    return sweep_dev(&a, logit, (hipStream_t)stream);
+}
+
 int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream)
 {
-    LOCUS_REQUIRE(workspace != nullptr && p >= 1, "sweep_status: bad arguments");
+    LOCUS_REQUIRE(p >= 1, "sweep_status: bad arguments");
+    if (workspace == nullptr) {  // the sweep ran on the static workspace of the current device
+        void* ptr = nullptr;
+        int rc = static_scratch_ptr(&ptr);
+        if (rc) return rc;
+        workspace = ptr;
+    }
     WsView ws = carve(const_cast<void*>(workspace), p);
     int herr = 0;
     LOCUS_HIP_CHECK(hipMemcpyAsync(&herr, ws.err, sizeof(int), hipMemcpyDeviceToHost,
