@@ -4,12 +4,116 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "mfma_sweep1_kernel.h"
 #include "mfma_sweep_kernel.h"
 
 namespace locus {
 
 int launch_mfma_sweep_t1(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
 int launch_mfma_sweep_t2(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
+int launch_mfma_sweep1_c1(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
+
+// ---------------------------------------------------------------------------
+// Block packing for mfma_sweep1_kernel (look-ahead of L blocks, NW = CS * 6 row groups).  One
+// workgroup per iteration slot b = 0 .. nblk + L - 1.  As pack_blocks_kernel, plus: the update
+// operands of block b go to iteration b + L; (lod, xtx) pairs and the Gram columns are laid out
+// for scalar loads; the cross-block Gram matrices X_b' X_{b-l}, l = 1 .. L-1, are written as the
+// four A operands (per lane) of a 16x16x16 product at ax[l - 1][b].
+// ---------------------------------------------------------------------------
+template <int L>
+__global__ void __launch_bounds__(256)
+pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ steps,
+                    double* __restrict__ XS, double* __restrict__ cg, double* __restrict__ ax,
+                    double* __restrict__ sc2, int* __restrict__ jidx, int ld, int KT, int nblk, int NW,
+                    int nsteps)
+{
+    extern __shared__ double pk_smem[];
+    double (*xt)[130] = reinterpret_cast<double (*)[130]>(pk_smem);               // block b
+    double (*xl)[130] = reinterpret_cast<double (*)[130]>(pk_smem + 16 * 130);    // blocks b-1 .. b-L+1
+    int* js = reinterpret_cast<int*>(pk_smem + (size_t)L * 16 * 130);             // [L][16]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nit = nblk + L;
+    const bool has = b < nblk;
+    if (tid < 16 * L) {
+        const int l = tid >> 4, t = tid & 15, bb = b - l;
+        // steps beyond the sweep (padding of the last block) get a zero column: every operand of
+        // their update is then 0 and so is their delta (the chain has no "inactive" select)
+        js[tid] = (bb >= 0 && 16 * bb + t < nsteps) ? steps[16 * bb + t].j : -1;
+    }
+    if (tid < 16) {
+        const bool act = 16 * b + tid < nsteps;
+        const StepRec st = act ? steps[16 * b + tid] : StepRec{0.0, 0.0, 0, 0};
+        jidx[16 * b + tid] = st.j;
+        sc2[(size_t)(16 * b + tid) * 2] = st.lod;
+        sc2[(size_t)(16 * b + tid) * 2 + 1] = st.xtx;
+    }
+    const int rows_pad = NW * 16 * KT;
+    const int NOP = 8 * KT;
+    const int gt = tid >> 4, gs = tid & 15;
+    double gacc = 0.0;
+    double xacc[4] = {0.0, 0.0, 0.0, 0.0};  // lags 1 .. L-1 (L <= 5)
+    __syncthreads();
+    for (int c0 = 0; c0 < rows_pad; c0 += 128) {
+        // all 8 L loads of this chunk are requested before the first one is used: a workgroup
+        // alone on its CU (83 KB of LDS at L = 5) must not pay one memory latency per load
+        double v[L][8];
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid + 256 * i;
+                const int col = e >> 7, rr = e & 127, row = c0 + rr;
+                const int j = js[16 * l + col];
+                v[l][i] = (j >= 0 && row < ld) ? Xp[(size_t)j * ld + row] : 0.0;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid + 256 * i;
+                const int col = e >> 7, rr = e & 127;
+                if (l == 0) xt[col][rr] = v[l][i];
+                else xl[16 * (l - 1) + col][rr] = v[l][i];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = tid + 256 * i;
+            const int ln = o & 63;
+            const int sub = (o >> 6) & 3;
+            const int gl = o >> 8;
+            const int gtile = (c0 >> 4) + gl;
+            if (gtile < NW * KT) {
+                const int wv = gtile / KT, ti = gtile - wv * KT;
+                const int oi = op_index(ti, sub, KT);
+                const double vd = xt[ln & 15][16 * gl + 4 * sub + (ln >> 4)];
+                const double vu = xt[4 * sub + (ln >> 4)][16 * gl + (ln & 15)];
+                {
+                    const int ot = 4 * KT + oi;
+                    XS[(((size_t)wv * nit + b) * NOP + (ot & ~1)) * 64 + ln * 2 + (ot & 1)] = vd;
+                }
+                if (has)
+                    XS[(((size_t)wv * nit + b + L) * NOP + (oi & ~1)) * 64 + ln * 2 + (oi & 1)] = vu;
+                if (b < L)
+                    XS[(((size_t)wv * nit + b) * NOP + (oi & ~1)) * 64 + ln * 2 + (oi & 1)] = 0.0;
+            }
+        }
+#pragma unroll 4
+        for (int rr = 0; rr < 128; ++rr) {
+            const double a = xt[gt][rr];
+            gacc = fma(a, xt[gs][rr], gacc);
+#pragma unroll
+            for (int l = 1; l < L; ++l) xacc[l - 1] = fma(a, xl[16 * (l - 1) + gs][rr], xacc[l - 1]);
+        }
+    }
+    cg[(size_t)b * 256 + gs * 16 + gt] = (gt > gs) ? gacc : 0.0;
+    // (X_b' X_{b-l})[t' = gt][s = gs]: A operand c = gs >> 2 of lane (gs & 3) * 16 + gt
+#pragma unroll
+    for (int l = 1; l < L; ++l)
+        ax[((size_t)(l - 1) * (nit + 1) + b) * 256 + ((gs & 3) * 16 + gt) * 4 + (gs >> 2)] = xacc[l - 1];
+}
 
 // ---------------------------------------------------------------------------
 // One workgroup per iteration slot b = 0 .. nblk + 1 of the sweep.  For b < nblk it gathers the
@@ -112,14 +216,43 @@ int mfma_kt_for(int64_t n, int T)
 }
 
 // bytes of the block-packed operands for a sweep over p covariates of n rows
+// 16-row tiles per matrix wave of mfma_sweep1_kernel for n rows cut over CS workgroups
+int mfma1_kt_for(int64_t n, int CS)
+{
+#define LOCUS_KT_ITEM(k) k,
+    static const int kts1[] = {LOCUS_MFMA_KTS_T1(LOCUS_KT_ITEM) 0};
+    static const int kts2[] = {LOCUS_MFMA1_KTS_C2(LOCUS_KT_ITEM) 0};
+#undef LOCUS_KT_ITEM
+    for (const int* kt = (CS == 1) ? kts1 : kts2; *kt; ++kt)
+        if ((int64_t)CS * 6 * 16 * *kt >= n) return *kt;
+    return 0;
+}
+
+// doubles of the mfma_sweep1_kernel layout for `nblk` blocks (largest look-ahead, both CS)
+static size_t mfma1_layout_doubles(int64_t n, size_t nblk, int cus)
+{
+    const int kt1 = mfma1_kt_for(n, 1), kt2 = mfma1_kt_for(n, 2);
+    const size_t nit = nblk + 5;
+    const size_t rows_pad = std::max((size_t)6 * 16 * kt1, (size_t)2 * 6 * 16 * kt2);
+    return nit * rows_pad * 32 + 2048      // XS (+ read-ahead slack)
+           + nit * 256                     // cg
+           + 4 * (nit + 1) * 256           // ax, lags 1..4
+           + 16 * nit * 2 + 256            // sc2
+           + 8 * nit + 256                 // jidx (ints)
+           + (size_t)cus * (kXRing + 1) * 256 + 256   // xbuf: <= cus members in flight
+           + (size_t)cus * 16 + 256;       // xflag (32 ints per member)
+}
+
 size_t mfma_workspace_bytes(int64_t n, int64_t p)
 {
     const size_t nit = ((size_t)p + 15) / 16 + 2;
     const int kt1 = mfma_kt_for(n, 1), kt2 = mfma_kt_for(n, 2);
     if (kt1 == 0) return 1024;  // the matrix-core sweep does not cover this n
     const size_t rows_pad = std::max((size_t)mfma_waves(1) * 16 * kt1, (size_t)mfma_waves(2) * 16 * kt2);
-    return sizeof(double) * (nit * rows_pad * 32 + 2 * nit * 256 + nit * 64) + sizeof(int) * 16 * nit +
-           64 * 1024;
+    const size_t old_layout = sizeof(double) * (nit * rows_pad * 32 + 2 * nit * 256 + nit * 64) +
+                              sizeof(int) * 16 * nit + 64 * 1024;
+    const size_t new_layout = sizeof(double) * mfma1_layout_doubles(n, ((size_t)p + 15) / 16, 512) + 4096;
+    return std::max(old_layout, new_layout);
 }
 
 size_t mfma_lds_bytes(int T)
@@ -198,6 +331,99 @@ static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, i
     }
 }
 
+// One launch sequence of mfma_sweep1_kernel over responses [k_begin, k_end): packs (if `pack`) and
+// launches clusters of CS workgroups, at most as many clusters per launch as are resident at once
+// (a cluster's members wait for each other, so every member must be on a CU at the same time).
+static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin, int k_end, bool pack,
+                            void* xb_ws, size_t xb_bytes, hipStream_t st)
+{
+    const int L = mfma1_lag(CS);
+    const int NW = CS * 6;
+    const int rows_pad = NW * 16 * KT;
+    if (KT <= 0 || rows_pad < prm.n) {
+        set_error("mfma sweep: geometry does not cover n rows");
+        return LOCUS_HIP_EINVAL;
+    }
+    const int cus = device_cus();
+    const int nblk = (prm.nsteps + 15) / 16;
+    const size_t nit = (size_t)nblk + L;
+    const size_t xs = nit * rows_pad * 32;
+    char* base = static_cast<char*>(xb_ws);
+    base += (256 - ((uintptr_t)base & 255)) & 255;
+    double* XS = reinterpret_cast<double*>(base);
+    double* cgp = XS + xs + 2048;
+    double* axp = cgp + nit * 256;
+    double* sc2 = axp + 4 * (nit + 1) * 256;
+    int* jidx = reinterpret_cast<int*>(sc2 + 16 * nit * 2 + 256);
+    double* xbuf = reinterpret_cast<double*>(jidx) + 8 * nit + 256;
+    int* xflag = reinterpret_cast<int*>(xbuf + (size_t)cus * (kXRing + 1) * 256 + 256);
+    const size_t used = (size_t)(reinterpret_cast<char*>(xflag) - static_cast<char*>(xb_ws)) +
+                        sizeof(int) * ((size_t)cus * 32 + 64);
+    if (used > xb_bytes) {
+        set_error("mfma sweep: workspace too small");
+        return LOCUS_HIP_EINVAL;
+    }
+    if (pack) {
+        const size_t lds = sizeof(double) * (size_t)L * 16 * 130 + sizeof(int) * 16 * L;
+        if (L == 3) {
+            hipLaunchKernelGGL(pack_blocks1_kernel<3>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
+                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps);
+        } else {
+            static bool attr_set = false;  // 83 KB of dynamic LDS: above the 64 KB default limit
+            if (!attr_set) {
+                LOCUS_HIP_CHECK(hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(pack_blocks1_kernel<5>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(pack_blocks1_kernel<5>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
+                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps);
+        }
+        LOCUS_HIP_CHECK(hipGetLastError());
+    }
+    Mfma1Params mp;
+    mp.n = prm.n; mp.p = prm.p; mp.d = prm.d;
+    mp.nblk = nblk; mp.nsteps = prm.nsteps;
+    mp.err = const_cast<int*>(prm.err);
+    mp.XS = XS; mp.cg = cgp; mp.ax = axp; mp.sc2 = sc2; mp.jidx = jidx;
+    mp.scale = prm.scale; mp.hinv = prm.hinv; mp.cst = prm.cst; mp.s2k = prm.s2k;
+    mp.cfac = prm.cfac;
+    mp.R = prm.R; mp.state = prm.state; mp.st = prm.st;
+    mp.xbuf = xbuf; mp.xflag = xflag;
+
+    // clusters resident at once: one workgroup per CU, members of a cluster 8 blocks apart
+    const int max_tiles = std::max(1, cus / (8 * CS)) * 8;
+    if (CS > 1 && cus < 8 * CS) {
+        set_error("mfma sweep: too few CUs for row-split clusters");
+        return LOCUS_HIP_EUNSUPPORTED;
+    }
+    for (int k = k_begin; k < k_end; k += 16 * max_tiles) {
+        const int ke = std::min(k_end, k + 16 * max_tiles);
+        mp.k_begin = k; mp.k_end = ke;
+        mp.ntiles = (ke - k + 15) / 16;
+        if (CS > 1)
+            LOCUS_HIP_CHECK(hipMemsetAsync(xflag, 0, sizeof(int) * (size_t)mp.ntiles * CS * 32, st));
+        dim3 grid((unsigned)(((mp.ntiles + 7) / 8) * 8 * CS));
+        const int rc = (CS == 1) ? launch_mfma_sweep1_c1(mp, KT, grid, st)
+                                 : launch_mfma_sweep1_c2(mp, KT, grid, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// row-split cluster size for `tiles` tiles of 16 responses: 2 when every member of every cluster
+// fits on the chip at once and n is covered, else 1.  LOCUS_HIP_MFMA_CS overrides (1 or 2).
+static int choose_cs(int n, int tiles)
+{
+    int want = 0;
+    if (const char* e = getenv("LOCUS_HIP_MFMA_CS")) want = atoi(e);
+    if (want == 1) return 1;
+    const int cus = device_cus();
+    const bool fits2 = mfma1_kt_for(n, 2) > 0 && cus >= 16;
+    if (want == 2) return fits2 ? 2 : 1;
+    return (fits2 && ((tiles + 7) / 8) * 8 * 2 <= cus) ? 2 : 1;
+}
+
 // cfg: C = T (tiles of 16 responses per workgroup; 0 = plan by d), G = KT (16-row tiles per matrix
 // wave, 0 = smallest instantiated value that covers n).
 // Planned mode: a workgroup holds its responses in the registers of a whole CU, so one launch
@@ -210,6 +436,13 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
     if (cfg.C < 0 || cfg.C > 2) {
         set_error("mfma sweep: bad geometry (T in 0..2)");
         return LOCUS_HIP_EINVAL;
+    }
+    const bool old1 = getenv("LOCUS_HIP_MFMA_OLD") != nullptr;  // A/B: round-1 T = 1 kernel
+    if (cfg.C == 1 && !old1) {  // one tile per cluster: mfma_sweep1_kernel, S = workgroups per cluster
+        // S = workgroups per cluster (1, 2); 0 = chosen from d; anything else (legacy) = 1
+        const int CS = (cfg.S == 2) ? 2 : (cfg.S == 0 ? choose_cs(prm.n, (prm.d + 15) / 16) : 1);
+        const int KT = cfg.G > 0 ? cfg.G : mfma1_kt_for(prm.n, CS);
+        return pack_and_launch1(prm, CS, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
     }
     if (cfg.C != 0) {
         const int KT = cfg.G > 0 ? cfg.G : mfma_kt_for(prm.n, cfg.C);
@@ -227,8 +460,14 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
         const int rem = prm.d - k;
         const int T = (kt2 > 0 && rem > cap1) ? 2 : 1;
         const int take = std::min(rem, T == 2 ? cap2 : cap1);
-        const int rc = pack_and_launch(prm, T, T == 2 ? kt2 : kt1, k, k + take, T != last_T, xb_ws,
-                                       xb_bytes, st);
+        int rc;
+        if (T == 2 || old1) {
+            rc = pack_and_launch(prm, T, T == 2 ? kt2 : kt1, k, k + take, T != last_T, xb_ws, xb_bytes, st);
+        } else {
+            const int CS = choose_cs(prm.n, (take + 15) / 16);
+            rc = pack_and_launch1(prm, CS, mfma1_kt_for(prm.n, CS), k, k + take, true, xb_ws, xb_bytes,
+                                  st);
+        }
         if (rc) return rc;
         last_T = T;
         k += take;

@@ -1,0 +1,582 @@
+// Matrix-core CAVI sweep for ONE tile of 16 responses per cluster of CS workgroups
+// (coreLoop / coreZLoop / coreStructLoop / coreProbitLoop, src/coreLoop.cpp:36-52,
+// coreStructLoop.cpp:34-50) -- the latency regime: d_loc <= 16 responses per CU (C2, C5, the
+// remainder of C3 on one GPU, every multi-GPU shard).
+//
+// Same blocked look-ahead restatement as mfma_sweep_kernel.h (blocks of 16 covariates,
+//     X_t' R^(t) = G_t + sum_{s<t} A_b[t][s] d_s,   G_b = X_b' R_(b-L) + sum_{l<L} (X_b' X_{b-l}) d_{b-l}),
+// re-cut so that the sequential element-wise chain carries nothing but the chain:
+//
+//   waves 0,1,2,4,5,6 (matrix role, SIMDs 0..2): rows of the residual tile as MFMA accumulators,
+//       X operands streamed from global memory in consumption order; matrix wave 0 also forms the
+//       cross-block corrections of the block the chain runs NEXT (lags L-1..2 from deltas that are
+//       known, lag 1 by following the chain's progress word) on top of the reduced G and leaves
+//       the chain its starting values gx[t][response];
+//   wave 3 (chain role, alone with the helper on SIMD 3): per step ONE LDS read of gx, ONE of
+//       beta_old, the step's scalars and Gram column through the scalar cache (s_load: they are
+//       wave-uniform), the update, three LDS writes (delta, mu, gamma).  No global memory access,
+//       no partial-sum tree, no address arithmetic;
+//   wave 7 (helper role): everything else, off the critical path -- sums the matrix waves' partial
+//       G tiles, exchanges them with the other workgroups of the cluster, stages beta_old, writes
+//       gam / mu / beta of the block the chain finished one iteration ago to global memory and
+//       accumulates the fused column statistics.
+//
+// Row-split clusters (CS > 1): the 16 responses' rows are cut over CS workgroups on CS CUs.  Each
+// member projects / updates its own rows, publishes its partial G tile (2 KB per block) through
+// global memory (agent-scope stores + a monotone flag, MI355X_MICROARCH.md "Valid forms", row 1),
+// and EVERY member runs the same chain on the same sums (added in member order, so the chains are
+// bit-identical and no delta ever has to travel).  The look-ahead is deepened to L = 5 blocks so
+// that a partial tile has two block times (~7 us) to arrive.  All waits are bounded: a partner that
+// does not show up raises the error word instead of hanging the GPU.
+#pragma once
+#include "mfma_sweep_kernel.h"
+
+namespace locus {
+
+struct Mfma1Params {
+    int n, p, d;
+    int k_begin, k_end;   // responses [k_begin, k_end) are swept by this launch
+    int ntiles;           // tiles of 16 responses = clusters
+    int nblk, nsteps;     // blocks of 16 steps, active steps
+    int* err;             // bit 0/1: bad permutation (prologue); bit 2: cluster partner timed out
+    const double* XS;     // [CS * 6][nit][8 KT][64] operand streams (pack_blocks_kernel), nit = nblk + L
+    const double* cg;     // [nit][16][16]  cg[b][t][t2] = X_t2' X_t of block b for t2 > t, else 0
+    const double* ax;     // [L - 1][nit + 1][64][4]  A operands of (X_b' X_{b-l}), l = 1 .. L-1
+    const double* sc2;    // [16 nit][2]   lod, xtx of every step (inactive steps: 0, 0)
+    const int* jidx;      // [16 nit]      covariate of every step (inactive: 0)
+    const double* scale;  // per-response constants, as SweepParams
+    const double* hinv;
+    const double* cst;
+    const double* s2k;
+    double cfac;
+    double* R;            // n x d column-major
+    double* state;        // [3][p][d]
+    double* st;           // [4][d] or nullptr
+    double* xbuf;         // CS > 1: [ntiles][kXRing + 1][CS][256] partial tiles (+ one slot for sum R^2)
+    int* xflag;           // CS > 1: [ntiles][CS][32] blocks published by each member (monotone)
+};
+
+constexpr int kXRing = 16;  // exchange slots per member; >= 2 L + 1 blocks can be in flight
+
+__host__ __device__ constexpr int mfma1_lag(int CS) { return CS == 1 ? 3 : 5; }
+
+template <int KT>
+constexpr int ring1_pairs()
+{
+    constexpr int cap = (KT > 18) ? 7 : 12;
+    int best = 1;
+    for (int r = 1; r <= cap; ++r)
+        if ((4 * KT) % r == 0) best = r;
+    return best;
+}
+
+__device__ __forceinline__ void lds_publish(int* word, int v)
+{
+    // LDS executes one wave's accesses in order: the data stores before this one are visible to
+    // whoever sees the new value
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int lds_peek(int* word)
+{
+    return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Eight agent-scope (sc1) 8-byte loads in flight together: v[i] = p[64 i] for the calling lane
+// (two members' partial tiles of 4 x 64 doubles each lie 256 doubles apart).  Requests and their
+// wait sit in ONE asm statement with early-clobber outputs: a destination register of a load that
+// is still in flight must never look free to the register allocator.
+__device__ __forceinline__ void sc1_load8(const double* p, double (&v)[8])
+{
+    asm volatile(
+        "global_load_dwordx2 %0, %8, off sc0 sc1\n\t"
+        "global_load_dwordx2 %1, %8, off offset:512 sc0 sc1\n\t"
+        "global_load_dwordx2 %2, %8, off offset:1024 sc0 sc1\n\t"
+        "global_load_dwordx2 %3, %8, off offset:1536 sc0 sc1\n\t"
+        "global_load_dwordx2 %4, %8, off offset:2048 sc0 sc1\n\t"
+        "global_load_dwordx2 %5, %8, off offset:2560 sc0 sc1\n\t"
+        "global_load_dwordx2 %6, %8, off offset:3072 sc0 sc1\n\t"
+        "global_load_dwordx2 %7, %8, off offset:3584 sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]),
+          "=&v"(v[7])
+        : "v"(p)
+        : "memory");
+}
+
+// Diagnostic build only (-DLOCUS_STAMPS): per-phase cycle sums, [workgroup][role][8]; role 0 =
+// matrix wave 0, 1 = matrix wave 5, 2 = chain, 3 = helper.  No stamp executes in the product build.
+#ifdef LOCUS_STAMPS
+__device__ unsigned long long g_mfma1_stamps[4096 * 4 * 8];
+#define M1STAMP(k)                                                                       \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        unsigned long long t_;                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+        tacc[k] += t_ - tprev;                                                           \
+        tprev = t_;                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#define M1STAMP_FLUSH(role)                                                              \
+    do {                                                                                 \
+        if (lane == 0 && blockIdx.x < 4096)                                              \
+            for (int k_ = 0; k_ < 8; ++k_)                                               \
+                g_mfma1_stamps[(blockIdx.x * 4 + (role)) * 8 + k_] = tacc[k_];           \
+    } while (0)
+#else
+#define M1STAMP(k) do { } while (0)
+#define M1STAMP_FLUSH(role) do { } while (0)
+#endif
+
+template <int KT, int CS>
+__global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
+{
+    constexpr int L = mfma1_lag(CS);
+    constexpr int MW = 6;
+    constexpr int NOP = 8 * KT, NPAIR = NOP / 2, NR2 = ring1_pairs<KT>();
+    static_assert(NPAIR % NR2 == 0, "ring must divide the iteration stream");
+    constexpr int DR = 8;       // delta ring, blocks (power of two, >= L)
+    constexpr int CHAIN_W = 3, HELP_W = 7;
+
+    __shared__ __align__(16) double part[2 * MW * 256];  // partial G per matrix wave   [par][m][g][lane]
+    __shared__ __align__(16) double gfin[256];           // reduced G of the next chain block, D layout
+    __shared__ __align__(16) double gx[2 * 256];         // chain starting values       [par][t][r]
+    __shared__ __align__(16) double dl[DR * 256];        // deltas                      [blk & 7][t][r]
+    __shared__ __align__(16) double mg[2 * 2 * 256];     // mu, gamma of a chain block  [par][2][t][r]
+    __shared__ __align__(16) double bol[2 * 256];        // beta_old                    [par][t][r]
+    __shared__ __align__(16) double gram[2 * 256];       // Gram columns of a chain block [par][t][t2]
+    __shared__ __align__(16) double scl[2 * 32];         // lod, xtx of its steps       [par][t][2]
+    __shared__ int prog;        // steps the chain has completed
+    __shared__ int gfin_ready;  // iteration whose gfin is complete
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r = lane & 15;
+    const int n = P.n, d = P.d;
+    const int nit = P.nblk + L;
+
+    // cluster g = tile of 16 responses, member c = slice of the rows; members of a cluster have
+    // equal blockIdx % 8 (same XCD under round-robin placement: speed only, never correctness)
+    const int bi = blockIdx.x;
+    const int g_cl = (bi / (8 * CS)) * 8 + (bi & 7);
+    const int c_mem = (bi >> 3) % CS;
+    if (g_cl >= P.ntiles || *P.err != 0) return;
+    const int k0 = P.k_begin + 16 * g_cl;
+    const int kend = P.k_end;
+    const size_t pd = (size_t)P.p * d;
+
+    for (int e = tid; e < DR * 256; e += 512) dl[e] = 0.0;
+    for (int e = tid; e < 512; e += 512) { gx[e] = 0.0; bol[e] = 0.0; }
+    for (int e = tid; e < 1024; e += 512) mg[e] = 0.0;
+    for (int e = tid; e < 512; e += 512) gram[e] = 0.0;
+    if (tid < 64) scl[tid] = 0.0;
+    if (tid == 0) { prog = 0; gfin_ready = -1; }
+    __syncthreads();
+#ifdef LOCUS_STAMPS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
+
+    if (w != CHAIN_W && w != HELP_W) {
+        // =========================== matrix role ==========================================
+        const int m = (w > CHAIN_W) ? w - 1 : w;
+        const int row0 = ((c_mem * MW + m) * KT) * 16;
+
+        d4 rv[KT];
+        {
+            const int k = k0 + r;
+            const double* Rk = P.R + (size_t)(k < kend ? k : 0) * n;
+#pragma unroll
+            for (int i = 0; i < KT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = row0 + 16 * i + 4 * g + q;
+                    rv[i][g] = (k < kend && row < n) ? Rk[row] : 0.0;
+                }
+        }
+        const double2* xp = reinterpret_cast<const double2*>(P.XS) +
+                            ((size_t)(c_mem * MW + m) * nit) * NPAIR * 64 + lane;
+        double2 ring[NR2];
+#pragma unroll
+        for (int i = 0; i < NR2; ++i) {
+            ring[i] = *xp;
+            xp += 64;
+        }
+        const size_t ax_lag = (size_t)(nit + 1) * 256;   // doubles per lag in P.ax
+
+        for (int it = 0; it < nit; ++it) {
+            const int par = it & 1;
+            __syncthreads();  // B1
+            M1STAMP(0);
+            double bop[4];
+            {
+                const double* dp = dl + ((it - L) & (DR - 1)) * 256 + q * 16 + r;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bop[c] = dp[64 * c];
+            }
+            // A operands of the cross-block corrections (matrix wave 0 only; used at the end)
+            const int bx = it - L + 2;  // block the chain runs in the NEXT iteration
+            const bool xw = (m == 0) && bx >= 0 && bx < P.nblk;
+            double2 axr[L - 1][2];
+            if (xw) {
+#pragma unroll
+                for (int l = 1; l < L; ++l) {
+                    const double2* ap = reinterpret_cast<const double2*>(
+                        P.ax + (size_t)(l - 1) * ax_lag + (size_t)bx * 256 + 4 * lane);
+                    axr[l - 1][0] = ap[0];
+                    axr[l - 1][1] = ap[1];
+                }
+            }
+
+            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+            auto slot = [&](auto oc) {
+                constexpr int o = decltype(oc)::value;
+                constexpr int sl = (o >> 1) % NR2;
+                const double a = (o & 1) ? ring[sl].y : ring[sl].x;
+                if constexpr ((o & 1) != 0) {
+                    ring[sl] = *xp;
+                    xp += 64;
+                }
+                if constexpr (o < 4 * KT) {  // R += X_{it-L} d_{it-L}
+                    constexpr int i = op_tile(o, KT), c = op_sub(o, KT);
+                    rv[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[c], rv[i], 0, 0, 0);
+                } else {                     // partial G_it = X_it' R over this wave's rows
+                    constexpr int i = op_tile(o - 4 * KT, KT), g = op_sub(o - 4 * KT, KT);
+                    acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rv[i][g], acc[i & 1], 0, 0, 0);
+                }
+            };
+            sfor<NOP>(slot);
+            M1STAMP(1);
+            {
+                double* pb = part + (par * MW + m) * 256 + lane;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pb[g * 64] = acc[0][g] + acc[1][g];
+            }
+            if (xw) {
+                // gx of block bx = reduced G (helper) + (X_bx' X_{bx-l}) d_{bx-l}, l = L-1 .. 1
+                for (int spin = 0; lds_peek(&gfin_ready) < it && spin < (1 << 22); ++spin)
+                    __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                M1STAMP(2);
+                d4 xc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xc[g] = gfin[g * 64 + lane];
+#pragma unroll
+                for (int l = L - 1; l >= 1; --l) {
+                    const double* dp = dl + ((bx - l) & (DR - 1)) * 256 + q * 16 + r;
+                    const double axv[4] = {axr[l - 1][0].x, axr[l - 1][0].y, axr[l - 1][1].x,
+                                           axr[l - 1][1].y};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (l == 1) {  // the chain is producing these deltas right now
+                            if (c == 0) M1STAMP(3);
+                            const int target = 16 * (bx - 1) + 4 * c + 4;
+                            for (int spin = 0; lds_peek(&prog) < target && spin < (1 << 22); ++spin)
+                                __builtin_amdgcn_s_sleep(1);
+                            asm volatile("" ::: "memory");
+                        }
+                        const double bq = dp[64 * c];
+                        xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], bq, xc, 0, 0, 0);
+                    }
+                }
+                double* go = gx + (bx & 1) * 256 + q * 16 + r;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) go[64 * g] = xc[g];
+                M1STAMP(4);
+            }
+        }
+#ifdef LOCUS_STAMPS
+        if (m == 0) M1STAMP_FLUSH(0);
+        if (m == 5) M1STAMP_FLUSH(1);
+#endif
+
+        __syncthreads();  // E1: everybody is done with `part`
+        int lane_e = lane, n_e = n, d_e = kend;
+        asm volatile("" : "+v"(lane_e));
+        asm volatile("" : "+s"(n_e), "+s"(d_e));
+        const int q_e = lane_e >> 4, r_e = lane_e & 15;
+        {
+            const int k = k0 + r_e;
+            double* Rk = P.R + (size_t)(k < d_e ? k : 0) * n_e;
+            double a0 = 0.0;
+#pragma unroll
+            for (int i = 0; i < KT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = row0 + 16 * i + 4 * g + q_e;
+                    const double v = rv[i][g];
+                    if (k < d_e && row < n_e) Rk[row] = v;
+                    a0 = fma(v, v, a0);
+                }
+            part[m * 64 + lane] = a0;
+        }
+        __syncthreads();  // E2
+    } else if (w == CHAIN_W) {
+        // =========================== chain role ===========================================
+        const int kc = k0 + lane;
+        const bool cvalid = (lane < 16) && (kc < kend);
+        double c_scale = 0.0, c_hinv = 0.0, c_cst = 0.0;
+        if (cvalid) {
+            c_scale = P.scale[kc];
+            c_hinv = P.hinv[kc];
+            c_cst = P.cst[kc];
+        }
+        const double cfac = P.cfac;
+
+        for (int it = 0; it < nit; ++it) {
+            __syncthreads();  // B1
+            M1STAMP(0);
+            const int b = it - L + 1;  // block whose chain runs now
+            if (b < 0 || b >= P.nblk) continue;
+            if (lane < 16) {
+                const double* gx_l = gx + (b & 1) * 256 + lane;
+                const double* bo_l = bol + (b & 1) * 256 + lane;
+                double* dl_w = dl + (b & (DR - 1)) * 256 + lane;
+                double* mg_w = mg + (b & 1) * 512 + lane;
+                const double* sc_b = scl + (b & 1) * 32;      // wave-uniform addresses: broadcast reads
+                const double* cg_b = gram + (b & 1) * 256;
+
+                double corr[kBlk];
+#pragma unroll
+                for (int t = 0; t < kBlk; ++t) corr[t] = 0.0;
+                double u_c = gx_l[0], bo_c = bo_l[0];
+                double2 sc_c = *reinterpret_cast<const double2*>(sc_b);
+                __builtin_amdgcn_sched_barrier(0);
+                sfor<kBlk>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    // requests for step t + 1
+                    double u_n = 0.0, bo_n = 0.0;
+                    double2 sc_n = make_double2(0.0, 0.0);
+                    if constexpr (t + 1 < kBlk) {
+                        u_n = gx_l[(t + 1) * 16];
+                        bo_n = bo_l[(t + 1) * 16];
+                        sc_n = *reinterpret_cast<const double2*>(sc_b + 2 * (t + 1));
+                    }
+                    // column t of the block's Gram matrix, entries t + 1 .. 15, as 16-byte pairs
+                    // (the pair that holds entry t + 1 may start at the zero diagonal entry)
+                    double gcol[kBlk];
+                    sfor<8 - ((t + 1) >> 1)>([&](auto c2) {
+                        constexpr int t2 = 2 * (((t + 1) >> 1) + decltype(c2)::value);
+                        const double2 g2 = *reinterpret_cast<const double2*>(cg_b + t * 16 + t2);
+                        gcol[t2] = g2.x;
+                        gcol[t2 + 1] = g2.y;
+                    });
+                    const double lod = sc_c.x, xtx = sc_c.y;
+
+                    const double u = u_c + corr[t];
+                    const double dot = fma(xtx, bo_c, u);
+                    const double m = c_scale * dot;                            // coreLoop.cpp:42-43
+                    const double a = cfac * ((lod - m * m * c_hinv) + c_cst);  // :45-46
+#if defined(EXP_NOCHAIN)
+                    const double e = a; const double gmv = 0.25 * e;
+#else
+                    const double e = exp_nonpos(-fabs(a));
+                    const double gmv = div_1to2((a >= 0.0) ? e : 1.0, 1.0 + e);
+#endif
+                    const double bn = m * gmv;                                 // :48
+                    // inactive steps / responses: beta_old is staged as 0 and every operand of m
+                    // is 0, so delta = 0 without a select
+                    const double delta = bo_c - bn;
+                    sfor<kBlk - 1 - t>([&](auto c2) {
+                        constexpr int t2 = t + 1 + decltype(c2)::value;
+                        corr[t2] = fma(gcol[t2], delta, corr[t2]);
+                    });
+                    dl_w[t * 16] = delta;
+                    mg_w[t * 16] = m;
+                    mg_w[256 + t * 16] = gmv;
+                    if constexpr ((t & 3) == 3) lds_publish(&prog, 16 * b + t + 1);
+                    u_c = u_n;
+                    bo_c = bo_n;
+                    sc_c = sc_n;
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            M1STAMP(1);
+        }
+        M1STAMP_FLUSH(2);
+        __syncthreads();  // E1
+        __syncthreads();  // E2
+    } else {
+        // =========================== helper role ==========================================
+        const int kh = k0 + r;
+        const bool kvalid = kh < kend;
+        const bool storer = (c_mem == 0);
+        double c_s2 = kvalid ? P.s2k[kh] : 0.0;
+        double acc_g = 0.0, acc_m2 = 0.0, acc_b2 = 0.0;
+        double* xb_tile = nullptr;
+        int* xf_tile = nullptr;
+        if constexpr (CS > 1) {
+            xb_tile = P.xbuf + (size_t)g_cl * (kXRing + 1) * CS * 256;
+            xf_tile = P.xflag + (size_t)g_cl * CS * 32;
+        }
+
+        for (int it = 0; it < nit; ++it) {
+            __syncthreads();  // B1
+            M1STAMP(0);
+            // ---- beta_old of the block the chain runs next iteration: request ------------------
+            const int bn_blk = it - L + 2;
+            double bo_v[4] = {0.0, 0.0, 0.0, 0.0};
+            double2 gr_v[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+            double2 sc_v = make_double2(0.0, 0.0);
+            if (bn_blk >= 0 && bn_blk < P.nblk) {   // its Gram columns and step scalars, too
+                const double2* gsrc = reinterpret_cast<const double2*>(P.cg + (size_t)256 * bn_blk) + 2 * lane;
+                gr_v[0] = gsrc[0];
+                gr_v[1] = gsrc[1];
+                if (lane < 16)
+                    sc_v = reinterpret_cast<const double2*>(P.sc2 + (size_t)32 * bn_blk)[lane];
+            }
+            if (bn_blk >= 0 && bn_blk < P.nblk && kvalid) {
+#pragma unroll
+                for (int rd = 0; rd < 4; ++rd) {
+                    const int s = 16 * bn_blk + 4 * rd + q;
+                    if (s < P.nsteps)
+                        bo_v[rd] = P.state[2 * pd + (size_t)P.jidx[s] * d + kh];
+                }
+            }
+            // ---- reduced G ------------------------------------------------------------------
+            if (it >= 1) {
+                const double* pp = part + (((it - 1) & 1) * MW) * 256 + lane;
+                double pg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const double* p2 = pp + g * 64;
+                    pg[g] = ((p2[0] + p2[256]) + (p2[512] + p2[768])) + (p2[1024] + p2[1280]);
+                }
+                if constexpr (CS == 1) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gfin[g * 64 + lane] = pg[g];
+                } else {
+                    static_assert(CS == 2, "sc1_load8 fetches exactly two members' tiles");
+                    // every member's tile of block bxg was published >= 2 iterations ago: check
+                    // the flags (normally no wait at all), fetch both tiles at once, add them in
+                    // member order (identical sums in every member)
+                    const int bxg = it - L + 2;
+                    double sg[4] = {0.0, 0.0, 0.0, 0.0};
+                    if (bxg >= 0 && bxg < P.nblk) {
+#pragma unroll
+                        for (int cm = 0; cm < CS; ++cm) {
+                            int spin = 0;
+                            while (__hip_atomic_load(xf_tile + cm * 32, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT) < bxg + 1) {
+                                __builtin_amdgcn_s_sleep(2);
+                                if (++spin > (1 << 21)) {  // ~0.2 s: the partner is not running
+                                    if (lane == 0) atomicOr(P.err, 4);
+                                    break;
+                                }
+                            }
+                        }
+                        double tv[8];
+                        sc1_load8(xb_tile + (size_t)(bxg % kXRing) * CS * 256 + lane, tv);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) sg[g] = tv[g] + tv[4 + g];
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gfin[g * 64 + lane] = sg[g];
+                }
+                M1STAMP(1);
+                lds_publish(&gfin_ready, it);
+                if constexpr (CS > 1) {
+                    // publish this member's partial tile of block it - 1
+                    if (it - 1 < P.nblk) {
+                        double* slot = xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * 256 + lane;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            __hip_atomic_store(slot + g * 64, pg[g], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0)
+                            __hip_atomic_store(xf_tile + c_mem * 32, it, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            } else {
+                M1STAMP(1);
+                lds_publish(&gfin_ready, it);
+            }
+            // ---- results of the block the chain finished last iteration -----------------------
+            const int bs = it - L;
+            if (storer && bs >= 0 && bs < P.nblk && kvalid) {
+                const double* mp = mg + (bs & 1) * 512 + q * 16 + r;
+#pragma unroll
+                for (int rd = 0; rd < 4; ++rd) {
+                    const int s = 16 * bs + 4 * rd + q;
+                    if (s < P.nsteps) {
+                        const double mv = mp[64 * rd], gv = mp[256 + 64 * rd];
+                        const double bv = mv * gv;
+                        double* o = P.state + (size_t)P.jidx[s] * d + kh;
+                        o[0] = gv;
+                        o[pd] = mv;
+                        o[2 * pd] = bv;
+                        acc_g += gv;
+                        acc_m2 = fma(gv, fma(mv, mv, c_s2), acc_m2);
+                        acc_b2 = fma(bv, bv, acc_b2);
+                    }
+                }
+            }
+            // ---- beta_old: hand over ------------------------------------------------------------
+            if (bn_blk >= 0 && bn_blk < P.nblk) {
+                double* bp = bol + (bn_blk & 1) * 256 + q * 16 + r;
+#pragma unroll
+                for (int rd = 0; rd < 4; ++rd) bp[64 * rd] = bo_v[rd];
+                double2* gp = reinterpret_cast<double2*>(gram + (bn_blk & 1) * 256) + 2 * lane;
+                gp[0] = gr_v[0];
+                gp[1] = gr_v[1];
+                if (lane < 16) reinterpret_cast<double2*>(scl + (bn_blk & 1) * 32)[lane] = sc_v;
+            }
+            M1STAMP(2);
+        }
+        M1STAMP_FLUSH(3);
+        __syncthreads();  // E1
+        // column statistics: sum the four step classes of a response through LDS (gfin is free)
+        gfin[lane] = acc_g;
+        gfin[64 + lane] = acc_m2;
+        gfin[128 + lane] = acc_b2;
+        __syncthreads();  // E2: the matrix waves' sums of squares are in `part`
+        double rss = 0.0;
+        if (lane < 16) {
+#pragma unroll
+            for (int ss = 0; ss < MW; ++ss) {
+                const double* pp = part + ss * 64 + lane;
+                rss += (pp[0] + pp[16]) + (pp[32] + pp[48]);
+            }
+        }
+        if constexpr (CS > 1) {
+            // sum of squares over the members' row slices, added in member order by member 0
+            double* slot = xb_tile + ((size_t)kXRing * CS + c_mem) * 256;
+            if (lane < 16) __hip_atomic_store(slot + lane, rss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(xf_tile + c_mem * 32, nit + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (storer) {
+                rss = 0.0;
+#pragma unroll
+                for (int cm = 0; cm < CS; ++cm) {
+                    int spin = 0;
+                    while (__hip_atomic_load(xf_tile + cm * 32, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT) < nit + 1) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spin > (1 << 21)) {
+                            if (lane == 0) atomicOr(P.err, 4);
+                            break;
+                        }
+                    }
+                    if (lane < 16)
+                        rss += __hip_atomic_load(xb_tile + ((size_t)kXRing * CS + cm) * 256 + lane,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (P.st != nullptr && storer && lane < 16 && kvalid) {
+            const double* sp = gfin + lane;
+            P.st[kh] = (sp[0] + sp[16]) + (sp[32] + sp[48]);
+            P.st[(size_t)d + kh] = (sp[64] + sp[80]) + (sp[96] + sp[112]);
+            P.st[2 * (size_t)d + kh] = (sp[128] + sp[144]) + (sp[160] + sp[176]);
+            P.st[3 * (size_t)d + kh] = rss;
+        }
+    }
+}
+
+}  // namespace locus

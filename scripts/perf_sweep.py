@@ -56,7 +56,25 @@ def main():
         cfg_used = (_lib.ctypes.c_int32 * 4)()
         _lib.lib().locus_hip_sweep_config(n, d, int(logit), cfg_used)
         upd = nsteps * d / (t * 1e-3)
-        if "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0:
+        if "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0 and cfg[1] == 1:
+            import ctypes
+            import os
+            cs_used = 2 if (cfg[2] == 2 or os.environ.get("LOCUS_HIP_MFMA_CS") == "2") else 1
+            fn = getattr(ctypes.CDLL(_lib.LIB_PATH), f"locus_hip_diag_read_mfma1_stamps_c{cs_used}")
+            nwg = min(4096, 2 * ((d + 15) // 16 + 8))
+            buf = (ctypes.c_ulonglong * (32 * nwg))()
+            fn(buf, 32 * nwg)
+            a = np.array(buf, dtype=np.float64).reshape(nwg, 4, 8)
+            a = a[a[:, 2, 1] > 0] / ((nsteps + 15) // 16)
+            roles = {0: ("matrix wave 0", ["B1-wait", "mfma", "gfin-wait", "corr(l>=2)", "follow+write"]),
+                     1: ("matrix wave 5", ["B1-wait", "mfma"]),
+                     2: ("chain", ["B1-wait", "run"]),
+                     3: ("helper", ["B1-wait", "reduce/xchg", "store/bol"])}
+            for ro, (nm, names) in roles.items():
+                med = np.median(a[:, ro, :len(names)], axis=0)
+                print(f"   ticks/block {nm:14s}: " + " ".join(f"{k}={v:.0f}" for k, v in zip(names, med))
+                      + f" total={med.sum():.0f}")
+        elif "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0:
             import ctypes
             fn = getattr(ctypes.CDLL(_lib.LIB_PATH), f"locus_hip_diag_read_mfma_stamps_{cfg[1]}")
             nwg = min(4096, (d + 16 * cfg[1] - 1) // (16 * cfg[1]))

@@ -82,14 +82,16 @@ def test_two_sweeps_in_a_row_deterministic(hip):
 
 # matrix-core kernel, explicit geometries -1,T,S,KW4 (T tiles of 16 responses per workgroup,
 # S waves, KW4 16-row tiles per wave): ragged rows / responses / last block of the sweep
-MFMA_GEOMS = ([f"-1,1,8,{kt}" for kt in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 18, 21)]
-              + [f"-1,2,8,{kt}" for kt in range(1, 12)] + ["-1,1,8,0", "-1,2,8,0"])
+MFMA_GEOMS = ([f"-1,1,1,{kt}" for kt in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 18, 21)]
+              + [f"-1,1,2,{kt}" for kt in range(1, 12)]          # rows cut over 2 workgroups
+              + [f"-1,2,8,{kt}" for kt in range(1, 12)] + ["-1,1,1,0", "-1,1,2,0", "-1,1,0,0", "-1,2,8,0"])
 
 
 @pytest.mark.parametrize("geom", MFMA_GEOMS)
 def test_mfma_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
-    _, t, _, kt = map(int, geom.split(","))
-    n = (6 if t == 1 else 7) * 16 * kt - 5 if kt else 300   # matrix waves x 16-row tiles
+    _, t, cs, kt = map(int, geom.split(","))
+    waves = 7 if t == 2 else (12 if cs == 2 else 6)         # matrix waves over the rows
+    n = min(waves * 16 * kt - 5, 2016) if kt else 300       # x 16-row tiles, ragged; kernel limit
     p, d = 53, 16 * t + 16 * t + 7    # 3 blocks + 5 steps; partial last workgroup / tile
     inp = inputs_for("identity", n, p, d, seed=21)
     ref = call_variant(oracle, "identity", inp)
@@ -103,7 +105,7 @@ def test_mfma_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
                                    (333, 1, 5), (500, 33, 70)])
 def test_mfma_sweep_variants(oracle, hip, variant, shape, monkeypatch):
     n, p, d = shape
-    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-1,{1 if d <= 16 else 2},8,0")
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-1,{1 if d <= 16 else 2},{2 if n >= 300 else 1},0")
     inp = inputs_for(variant, n, p, d, seed=n + p + d, c=0.6 if variant == "identity" else 1.0)
     ref = call_variant(oracle, variant, inp)
     got = call_variant(hip, variant, inp)
