@@ -239,7 +239,7 @@ static size_t mfma1_layout_doubles(int64_t n, size_t nblk, int cus)
            + 4 * (nit + 1) * 256           // ax, lags 1..4
            + 16 * nit * 2 + 256            // sc2
            + 8 * nit + 256                 // jidx (ints)
-           + (size_t)cus * (kXRing + 1) * 256 + 256   // xbuf: <= cus members in flight
+           + (size_t)cus * (xbuf_tile_words(2) / 2) + 256   // xbuf: <= cus members in flight
            + (size_t)cus * 16 + 256;       // xflag (32 ints per member)
 }
 
@@ -251,7 +251,7 @@ size_t mfma_workspace_bytes(int64_t n, int64_t p)
     const size_t rows_pad = std::max((size_t)mfma_waves(1) * 16 * kt1, (size_t)mfma_waves(2) * 16 * kt2);
     const size_t old_layout = sizeof(double) * (nit * rows_pad * 32 + 2 * nit * 256 + nit * 64) +
                               sizeof(int) * 16 * nit + 64 * 1024;
-    const size_t new_layout = sizeof(double) * mfma1_layout_doubles(n, ((size_t)p + 15) / 16, 512) + 4096;
+    const size_t new_layout = sizeof(double) * mfma1_layout_doubles(n, ((size_t)p + 15) / 16, device_cus()) + 4096;
     return std::max(old_layout, new_layout);
 }
 
@@ -355,8 +355,8 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
     double* axp = cgp + nit * 256;
     double* sc2 = axp + 4 * (nit + 1) * 256;
     int* jidx = reinterpret_cast<int*>(sc2 + 16 * nit * 2 + 256);
-    double* xbuf = reinterpret_cast<double*>(jidx) + 8 * nit + 256;
-    int* xflag = reinterpret_cast<int*>(xbuf + (size_t)cus * (kXRing + 1) * 256 + 256);
+    unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(jidx) + 8 * nit + 256;
+    int* xflag = reinterpret_cast<int*>(xbuf + (size_t)cus * (xbuf_tile_words(2) / 2) + 256);
     const size_t used = (size_t)(reinterpret_cast<char*>(xflag) - static_cast<char*>(xb_ws)) +
                         sizeof(int) * ((size_t)cus * 32 + 64);
     if (used > xb_bytes) {
@@ -401,8 +401,11 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
         const int ke = std::min(k_end, k + 16 * max_tiles);
         mp.k_begin = k; mp.k_end = ke;
         mp.ntiles = (ke - k + 15) / 16;
-        if (CS > 1)
+        if (CS > 1) {  // a granule / flag is valid when it carries this launch's tag: start from zero
+            LOCUS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * mp.ntiles *
+                                                        xbuf_tile_words(CS), st));
             LOCUS_HIP_CHECK(hipMemsetAsync(xflag, 0, sizeof(int) * (size_t)mp.ntiles * CS * 32, st));
+        }
         dim3 grid((unsigned)(((mp.ntiles + 7) / 8) * 8 * CS));
         const int rc = (CS == 1) ? launch_mfma_sweep1_c1(mp, KT, grid, st)
                                  : launch_mfma_sweep1_c2(mp, KT, grid, st);

@@ -52,18 +52,25 @@ struct Mfma1Params {
     double* R;            // n x d column-major
     double* state;        // [3][p][d]
     double* st;           // [4][d] or nullptr
-    double* xbuf;         // CS > 1: [ntiles][kXRing + 1][CS][256] partial tiles (+ one slot for sum R^2)
-    int* xflag;           // CS > 1: [ntiles][CS][32] blocks published by each member (monotone)
+    // CS > 1: exchange of the members' partial G tiles, [ntiles][kXTile] 8-byte words per cluster:
+    // kXRing slots x CS members x 512 granules {32 bits of a double, tag = block + 1} (zeroed by the
+    // host before every launch: a granule is valid when its tag matches), then CS x 64 doubles for
+    // the members' sums of squares of the residual at the end of the sweep
+    unsigned long long* xbuf;
+    int* xflag;           // CS > 1: [ntiles][CS][32] end-of-sweep flags of the members
 };
 
 constexpr int kXRing = 16;  // exchange slots per member; >= 2 L + 1 blocks can be in flight
+__host__ __device__ constexpr size_t xbuf_tile_words(int CS) { return (size_t)kXRing * CS * 512 + CS * 64; }
 
 __host__ __device__ constexpr int mfma1_lag(int CS) { return CS == 1 ? 3 : 5; }
 
 template <int KT>
 constexpr int ring1_pairs()
 {
-    constexpr int cap = (KT > 18) ? 7 : 12;
+    // X operand pairs in flight per matrix wave (must divide 4 KT); the deep tiles keep fewer so
+    // that the residual (8 KT registers) and the ring fit 256 registers without spilling
+    constexpr int cap = (KT > 14 || KT <= 6) ? 6 : 12;
     int best = 1;
     for (int r = 1; r <= cap; ++r)
         if ((4 * KT) % r == 0) best = r;
@@ -80,28 +87,6 @@ __device__ __forceinline__ void lds_publish(int* word, int v)
 __device__ __forceinline__ int lds_peek(int* word)
 {
     return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// Eight agent-scope (sc1) 8-byte loads in flight together: v[i] = p[64 i] for the calling lane
-// (two members' partial tiles of 4 x 64 doubles each lie 256 doubles apart).  Requests and their
-// wait sit in ONE asm statement with early-clobber outputs: a destination register of a load that
-// is still in flight must never look free to the register allocator.
-__device__ __forceinline__ void sc1_load8(const double* p, double (&v)[8])
-{
-    asm volatile(
-        "global_load_dwordx2 %0, %8, off sc0 sc1\n\t"
-        "global_load_dwordx2 %1, %8, off offset:512 sc0 sc1\n\t"
-        "global_load_dwordx2 %2, %8, off offset:1024 sc0 sc1\n\t"
-        "global_load_dwordx2 %3, %8, off offset:1536 sc0 sc1\n\t"
-        "global_load_dwordx2 %4, %8, off offset:2048 sc0 sc1\n\t"
-        "global_load_dwordx2 %5, %8, off offset:2560 sc0 sc1\n\t"
-        "global_load_dwordx2 %6, %8, off offset:3072 sc0 sc1\n\t"
-        "global_load_dwordx2 %7, %8, off offset:3584 sc0 sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]),
-          "=&v"(v[7])
-        : "v"(p)
-        : "memory");
 }
 
 // Diagnostic build only (-DLOCUS_STAMPS): per-phase cycle sums, [workgroup][role][8]; role 0 =
@@ -146,6 +131,12 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     __shared__ __align__(16) double bol[2 * 256];        // beta_old                    [par][t][r]
     __shared__ __align__(16) double gram[2 * 256];       // Gram columns of a chain block [par][t][t2]
     __shared__ __align__(16) double scl[2 * 32];         // lod, xtx of its steps       [par][t][2]
+    // CS > 1: A operands of the cross-block corrections of a block, staged by the helper [par][lag][lane][4]
+    __shared__ __align__(16) double axl[(CS > 1) ? 2 * (L - 1) * 256 : 2];
+    // CS > 1: corrections of the lags 2 .. L-1 (matrix waves 1 .. L-2), D layout, and their flags
+    __shared__ __align__(16) double cx[(CS > 1) ? (L - 2) * 256 : 2];
+    __shared__ int cxf[4];
+    __shared__ int jl[8 * 16];  // covariate of the steps of the blocks around the chain [blk & 7][t]
     __shared__ int prog;        // steps the chain has completed
     __shared__ int gfin_ready;  // iteration whose gfin is complete
 
@@ -171,7 +162,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     for (int e = tid; e < 1024; e += 512) mg[e] = 0.0;
     for (int e = tid; e < 512; e += 512) gram[e] = 0.0;
     if (tid < 64) scl[tid] = 0.0;
+    if (tid < 128) jl[tid] = 0;
     if (tid == 0) { prog = 0; gfin_ready = -1; }
+    if (tid < 4) cxf[tid] = -1;
     __syncthreads();
 #ifdef LOCUS_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -216,11 +209,38 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) bop[c] = dp[64 * c];
             }
-            // A operands of the cross-block corrections (matrix wave 0 only; used at the end)
-            const int bx = it - L + 2;  // block the chain runs in the NEXT iteration
-            const bool xw = (m == 0) && bx >= 0 && bx < P.nblk;
-            double2 axr[L - 1][2];
-            if (xw) {
+            // Cross-block corrections of block bx, the one the chain runs in the NEXT iteration:
+            //   gx = reduced G (helper) + sum_l (X_bx' X_{bx-l}) d_{bx-l},  l = 1 .. L-1.
+            // One workgroup per tile (CS = 1): matrix wave 0 does all of them at the end of its
+            // iteration.  Clusters: the lags >= 2, whose deltas are known, are spread over matrix waves
+            // 1 .. L-2 (one lag each, right after the barrier, A operands staged in LDS by the
+            // helper); wave 0 adds them up and is left with lag 1, which follows the chain.
+            const int bx = it - L + 2;
+            const bool bx_ok = bx >= 0 && bx < P.nblk;
+            const bool xw = (m == 0) && bx_ok;
+            double2 axr[(CS > 1) ? 1 : L - 1][2];
+            if constexpr (CS > 1) {
+                if (bx_ok && m <= L - 2) {
+                    // this wave's lag: m == 0 -> 1 (used at the end), m >= 1 -> m + 1 (used now)
+                    const int lagi = (m == 0) ? 0 : m;  // index l - 1
+                    const double2* ap =
+                        reinterpret_cast<const double2*>(axl + ((bx & 1) * (L - 1) + lagi) * 256) + 2 * lane;
+                    axr[0][0] = ap[0];
+                    axr[0][1] = ap[1];
+                    if (m >= 1) {
+                        const double* dp = dl + ((bx - (m + 1)) & (DR - 1)) * 256 + q * 16 + r;
+                        const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
+                        d4 cc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            cc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], dp[64 * c], cc, 0, 0, 0);
+                        double* co = cx + (m - 1) * 256 + lane;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) co[64 * g] = cc[g];
+                        lds_publish(&cxf[m - 1], it);
+                    }
+                }
+            } else if (xw) {  // used at the end of this iteration only
 #pragma unroll
                 for (int l = 1; l < L; ++l) {
                     const double2* ap = reinterpret_cast<const double2*>(
@@ -229,7 +249,6 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     axr[l - 1][1] = ap[1];
                 }
             }
-
             d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
             auto slot = [&](auto oc) {
                 constexpr int o = decltype(oc)::value;
@@ -255,7 +274,6 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 for (int g = 0; g < 4; ++g) pb[g * 64] = acc[0][g] + acc[1][g];
             }
             if (xw) {
-                // gx of block bx = reduced G (helper) + (X_bx' X_{bx-l}) d_{bx-l}, l = L-1 .. 1
                 for (int spin = 0; lds_peek(&gfin_ready) < it && spin < (1 << 22); ++spin)
                     __builtin_amdgcn_s_sleep(1);
                 asm volatile("" ::: "memory");
@@ -263,23 +281,37 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 d4 xc;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) xc[g] = gfin[g * 64 + lane];
+                if constexpr (CS > 1) {
 #pragma unroll
-                for (int l = L - 1; l >= 1; --l) {
-                    const double* dp = dl + ((bx - l) & (DR - 1)) * 256 + q * 16 + r;
-                    const double axv[4] = {axr[l - 1][0].x, axr[l - 1][0].y, axr[l - 1][1].x,
-                                           axr[l - 1][1].y};
+                    for (int l = 2; l < L; ++l) {   // fixed order: identical sums in every member
+                        for (int spin = 0; lds_peek(&cxf[l - 2]) < it && spin < (1 << 22); ++spin)
+                            __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (l == 1) {  // the chain is producing these deltas right now
-                            if (c == 0) M1STAMP(3);
-                            const int target = 16 * (bx - 1) + 4 * c + 4;
-                            for (int spin = 0; lds_peek(&prog) < target && spin < (1 << 22); ++spin)
-                                __builtin_amdgcn_s_sleep(1);
-                            asm volatile("" ::: "memory");
-                        }
-                        const double bq = dp[64 * c];
-                        xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], bq, xc, 0, 0, 0);
+                        for (int g = 0; g < 4; ++g) xc[g] += cx[(l - 2) * 256 + g * 64 + lane];
                     }
+                } else {
+#pragma unroll
+                    for (int l = L - 1; l >= 2; --l) {
+                        const double* dp2 = dl + ((bx - l) & (DR - 1)) * 256 + q * 16 + r;
+                        const double axv2[4] = {axr[l - 1][0].x, axr[l - 1][0].y, axr[l - 1][1].x,
+                                                axr[l - 1][1].y};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv2[c], dp2[64 * c], xc, 0, 0, 0);
+                    }
+                }
+                M1STAMP(3);
+                // lag 1: the chain is producing these deltas right now
+                const double* dp = dl + ((bx - 1) & (DR - 1)) * 256 + q * 16 + r;
+                const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int target = 16 * (bx - 1) + 4 * c + 4;
+                    for (int spin = 0; lds_peek(&prog) < target && spin < (1 << 22); ++spin)
+                        __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], dp[64 * c], xc, 0, 0, 0);
                 }
                 double* go = gx + (bx & 1) * 256 + q * 16 + r;
 #pragma unroll
@@ -405,117 +437,132 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         const bool storer = (c_mem == 0);
         double c_s2 = kvalid ? P.s2k[kh] : 0.0;
         double acc_g = 0.0, acc_m2 = 0.0, acc_b2 = 0.0;
-        double* xb_tile = nullptr;
+        unsigned long long* xb_tile = nullptr;
         int* xf_tile = nullptr;
         if constexpr (CS > 1) {
-            xb_tile = P.xbuf + (size_t)g_cl * (kXRing + 1) * CS * 256;
+            xb_tile = P.xbuf + (size_t)g_cl * xbuf_tile_words(CS);
             xf_tile = P.xflag + (size_t)g_cl * CS * 32;
         }
+
+        // CS > 1: the members' partial tiles of the block whose reduced G is due in the NEXT
+        // iteration, as granules {half a double, tag}: fetched one iteration ahead, validated (and
+        // in the rare case of a late partner re-fetched) when they are due
+        unsigned long long gv[(CS > 1) ? CS * 8 : 1];
+#pragma unroll
+        for (int e = 0; e < ((CS > 1) ? CS * 8 : 1); ++e) gv[e] = 0ull;
 
         for (int it = 0; it < nit; ++it) {
             __syncthreads();  // B1
             M1STAMP(0);
-            // ---- beta_old of the block the chain runs next iteration: request ------------------
-            const int bn_blk = it - L + 2;
+            const int bn_blk = it - L + 2;   // block the chain runs in the next iteration
+            const int bs = it - L;           // block the chain finished in the last iteration
+            double pg[4] = {0.0, 0.0, 0.0, 0.0};
+            // ---- reduced G of block bn_blk ---------------------------------------------------------
+            if constexpr (CS == 1) {
+                if (it >= 1) {
+                    const double* pp = part + (((it - 1) & 1) * MW) * 256 + lane;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double* p2 = pp + g * 64;
+                        pg[g] = ((p2[0] + p2[256]) + (p2[512] + p2[768])) + (p2[1024] + p2[1280]);
+                        gfin[g * 64 + lane] = pg[g];
+                    }
+                }
+            } else {
+                double sg[4] = {0.0, 0.0, 0.0, 0.0};
+                if (bn_blk >= 0 && bn_blk < P.nblk) {
+                    const unsigned tag = (unsigned)bn_blk + 1u;
+                    const unsigned long long* gsrc =
+                        xb_tile + (size_t)(bn_blk % kXRing) * CS * 512 + lane;
+                    for (int spin = 0;; ++spin) {
+                        bool ok = true;
+#pragma unroll
+                        for (int e = 0; e < CS * 8; ++e) ok = ok && ((unsigned)(gv[e] >> 32) == tag);
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if (spin > (1 << 19)) {  // ~0.5 s: the partner is not running
+                            if (lane == 0) atomicOr(P.err, 4);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+                        for (int e = 0; e < CS * 8; ++e)
+                            gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int cm = 0; cm < CS; ++cm)   // member order: identical sums in every member
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const unsigned long long lo = gv[cm * 8 + 2 * g] & 0xffffffffull;
+                            const unsigned long long hi = gv[cm * 8 + 2 * g + 1] << 32;
+                            sg[g] += __longlong_as_double((long long)(hi | lo));
+                        }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gfin[g * 64 + lane] = sg[g];
+            }
+            M1STAMP(1);
+            lds_publish(&gfin_ready, it);
+
+            // ---- requests: everything this iteration needs from global memory, at once -----------
             double bo_v[4] = {0.0, 0.0, 0.0, 0.0};
             double2 gr_v[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
             double2 sc_v = make_double2(0.0, 0.0);
-            if (bn_blk >= 0 && bn_blk < P.nblk) {   // its Gram columns and step scalars, too
-                const double2* gsrc = reinterpret_cast<const double2*>(P.cg + (size_t)256 * bn_blk) + 2 * lane;
+            int jv = 0;
+            const int jn_blk = bn_blk + 1;   // its covariates are staged one more iteration ahead
+            if (lane < 16 && jn_blk >= 0 && jn_blk < P.nblk) jv = P.jidx[16 * jn_blk + lane];
+            double2 ax_v[(CS > 1) ? L - 1 : 1][2];
+#pragma unroll
+            for (int l = 0; l < ((CS > 1) ? L - 1 : 1); ++l)
+                ax_v[l][0] = ax_v[l][1] = make_double2(0.0, 0.0);
+            if constexpr (CS > 1) {  // and the A operands of its cross-block corrections
+                if (jn_blk >= 0 && jn_blk < P.nblk) {
+#pragma unroll
+                    for (int l = 1; l < L; ++l) {
+                        const double2* ap = reinterpret_cast<const double2*>(
+                            P.ax + ((size_t)(l - 1) * (nit + 1) + jn_blk) * 256 + 4 * lane);
+                        ax_v[l - 1][0] = ap[0];
+                        ax_v[l - 1][1] = ap[1];
+                    }
+                }
+            }
+            if (bn_blk >= 0 && bn_blk < P.nblk) {
+                const double2* gsrc =
+                    reinterpret_cast<const double2*>(P.cg + (size_t)256 * bn_blk) + 2 * lane;
                 gr_v[0] = gsrc[0];
                 gr_v[1] = gsrc[1];
                 if (lane < 16)
                     sc_v = reinterpret_cast<const double2*>(P.sc2 + (size_t)32 * bn_blk)[lane];
-            }
-            if (bn_blk >= 0 && bn_blk < P.nblk && kvalid) {
+                if (kvalid) {
+                    const int* jp = jl + (bn_blk & 7) * 16 + q;
 #pragma unroll
-                for (int rd = 0; rd < 4; ++rd) {
-                    const int s = 16 * bn_blk + 4 * rd + q;
-                    if (s < P.nsteps)
-                        bo_v[rd] = P.state[2 * pd + (size_t)P.jidx[s] * d + kh];
+                    for (int rd = 0; rd < 4; ++rd)
+                        if (16 * bn_blk + 4 * rd + q < P.nsteps)
+                            bo_v[rd] = P.state[2 * pd + (size_t)jp[4 * rd] * d + kh];
                 }
             }
-            // ---- reduced G ------------------------------------------------------------------
-            if (it >= 1) {
-                const double* pp = part + (((it - 1) & 1) * MW) * 256 + lane;
-                double pg[4];
+            if constexpr (CS > 1) {
+                // ---- granules of the block due next iteration (published a whole iteration ago) ---
+                const int bg = bn_blk + 1;
+                if (bg >= 0 && bg < P.nblk) {
+                    const unsigned long long* gsrc = xb_tile + (size_t)(bg % kXRing) * CS * 512 + lane;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const double* p2 = pp + g * 64;
-                    pg[g] = ((p2[0] + p2[256]) + (p2[512] + p2[768])) + (p2[1024] + p2[1280]);
+                    for (int e = 0; e < CS * 8; ++e)
+                        gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if constexpr (CS == 1) {
+                // ---- this member's partial tile of block it - 1: reduce (published below) --------
+                if (it >= 1 && it - 1 < P.nblk) {
+                    const double* pp = part + (((it - 1) & 1) * MW) * 256 + lane;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gfin[g * 64 + lane] = pg[g];
-                } else {
-                    static_assert(CS == 2, "sc1_load8 fetches exactly two members' tiles");
-                    // every member's tile of block bxg was published >= 2 iterations ago: check
-                    // the flags (normally no wait at all), fetch both tiles at once, add them in
-                    // member order (identical sums in every member)
-                    const int bxg = it - L + 2;
-                    double sg[4] = {0.0, 0.0, 0.0, 0.0};
-                    if (bxg >= 0 && bxg < P.nblk) {
-#pragma unroll
-                        for (int cm = 0; cm < CS; ++cm) {
-                            int spin = 0;
-                            while (__hip_atomic_load(xf_tile + cm * 32, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT) < bxg + 1) {
-                                __builtin_amdgcn_s_sleep(2);
-                                if (++spin > (1 << 21)) {  // ~0.2 s: the partner is not running
-                                    if (lane == 0) atomicOr(P.err, 4);
-                                    break;
-                                }
-                            }
-                        }
-                        double tv[8];
-                        sc1_load8(xb_tile + (size_t)(bxg % kXRing) * CS * 256 + lane, tv);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) sg[g] = tv[g] + tv[4 + g];
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) gfin[g * 64 + lane] = sg[g];
-                }
-                M1STAMP(1);
-                lds_publish(&gfin_ready, it);
-                if constexpr (CS > 1) {
-                    // publish this member's partial tile of block it - 1
-                    if (it - 1 < P.nblk) {
-                        double* slot = xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * 256 + lane;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            __hip_atomic_store(slot + g * 64, pg[g], __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0)
-                            __hip_atomic_store(xf_tile + c_mem * 32, it, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            } else {
-                M1STAMP(1);
-                lds_publish(&gfin_ready, it);
-            }
-            // ---- results of the block the chain finished last iteration -----------------------
-            const int bs = it - L;
-            if (storer && bs >= 0 && bs < P.nblk && kvalid) {
-                const double* mp = mg + (bs & 1) * 512 + q * 16 + r;
-#pragma unroll
-                for (int rd = 0; rd < 4; ++rd) {
-                    const int s = 16 * bs + 4 * rd + q;
-                    if (s < P.nsteps) {
-                        const double mv = mp[64 * rd], gv = mp[256 + 64 * rd];
-                        const double bv = mv * gv;
-                        double* o = P.state + (size_t)P.jidx[s] * d + kh;
-                        o[0] = gv;
-                        o[pd] = mv;
-                        o[2 * pd] = bv;
-                        acc_g += gv;
-                        acc_m2 = fma(gv, fma(mv, mv, c_s2), acc_m2);
-                        acc_b2 = fma(bv, bv, acc_b2);
+                    for (int g = 0; g < 4; ++g) {
+                        const double* p2 = pp + g * 64;
+                        pg[g] = ((p2[0] + p2[256]) + (p2[512] + p2[768])) + (p2[1024] + p2[1280]);
                     }
                 }
             }
-            // ---- beta_old: hand over ------------------------------------------------------------
+            // ---- hand over what was requested: the ONE wait for global memory of this iteration.
+            // Every store of the iteration comes after it (the memory counter is in order: a wait
+            // for these loads behind the stores would also wait for the stores' write-through).
+            __builtin_amdgcn_sched_barrier(0);
             if (bn_blk >= 0 && bn_blk < P.nblk) {
                 double* bp = bol + (bn_blk & 1) * 256 + q * 16 + r;
 #pragma unroll
@@ -524,6 +571,57 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 gp[0] = gr_v[0];
                 gp[1] = gr_v[1];
                 if (lane < 16) reinterpret_cast<double2*>(scl + (bn_blk & 1) * 32)[lane] = sc_v;
+            }
+            if (lane < 16) jl[(jn_blk & 7) * 16 + lane] = jv;
+            if constexpr (CS > 1) {
+                if (jn_blk >= 0 && jn_blk < P.nblk) {
+                    double2* ap = reinterpret_cast<double2*>(axl + (jn_blk & 1) * (L - 1) * 256) + 2 * lane;
+#pragma unroll
+                    for (int l = 0; l < L - 1; ++l) {
+                        ap[128 * l] = ax_v[l][0];
+                        ap[128 * l + 1] = ax_v[l][1];
+                    }
+                }
+                // the granules just fetched are complete as well: pin them before the stores
+#pragma unroll
+                for (int e = 0; e < CS * 8; ++e) asm volatile("" : "+v"(gv[e]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CS > 1) {
+                // ---- publish this member's partial tile of block it - 1 ---------------------------
+                if (it >= 1 && it - 1 < P.nblk) {
+                    const unsigned long long tagw = (unsigned long long)(unsigned)it << 32;  // block + 1
+                    unsigned long long* slot =
+                        xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * 512 + lane;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(pg[g]);
+                        __hip_atomic_store(slot + 64 * (2 * g), tagw | (bits & 0xffffffffull),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(slot + 64 * (2 * g + 1), tagw | (bits >> 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            // ---- results of the block the chain finished last iteration -----------------------
+            if (storer && bs >= 0 && bs < P.nblk && kvalid) {
+                const double* mp = mg + (bs & 1) * 512 + q * 16 + r;
+                const int* jp = jl + (bs & 7) * 16 + q;
+#pragma unroll
+                for (int rd = 0; rd < 4; ++rd) {
+                    const int s = 16 * bs + 4 * rd + q;
+                    if (s < P.nsteps) {
+                        const double mv = mp[64 * rd], gv2 = mp[256 + 64 * rd];
+                        const double bv = mv * gv2;
+                        double* o = P.state + (size_t)jp[4 * rd] * d + kh;
+                        o[0] = gv2;
+                        o[pd] = mv;
+                        o[2 * pd] = bv;
+                        acc_g += gv2;
+                        acc_m2 = fma(gv2, fma(mv, mv, c_s2), acc_m2);
+                        acc_b2 = fma(bv, bv, acc_b2);
+                    }
+                }
             }
             M1STAMP(2);
         }
@@ -544,8 +642,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         }
         if constexpr (CS > 1) {
             // sum of squares over the members' row slices, added in member order by member 0
-            double* slot = xb_tile + ((size_t)kXRing * CS + c_mem) * 256;
-            if (lane < 16) __hip_atomic_store(slot + lane, rss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double* rs_base = reinterpret_cast<double*>(xb_tile + (size_t)kXRing * CS * 512);
+            if (lane < 16)
+                __hip_atomic_store(rs_base + c_mem * 64 + lane, rss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_store(xf_tile + c_mem * 32, nit + 1, __ATOMIC_RELAXED,
@@ -564,8 +663,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                         }
                     }
                     if (lane < 16)
-                        rss += __hip_atomic_load(xb_tile + ((size_t)kXRing * CS + cm) * 256 + lane,
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        rss += __hip_atomic_load(rs_base + cm * 64 + lane, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }

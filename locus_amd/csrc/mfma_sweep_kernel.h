@@ -83,7 +83,7 @@ __host__ __device__ constexpr int op_index(int i, int c, int KT)
 // whose 4 KT has no divisor near the ring cap (13, 17, 19, 20) are left out.  One list for the
 // host-side choice (mfma_sweep.hip) and the dispatch (mfma_sweep_inst.inc).
 #define LOCUS_MFMA_KTS_T1(X) \
-    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(14) X(15) X(16) X(18) X(21)
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(14) X(16) X(18) X(21)
 #define LOCUS_MFMA_KTS_T2(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
 // mfma_sweep1_kernel with the rows cut over 2 workgroups (12 matrix waves): n <= 2112
 #define LOCUS_MFMA1_KTS_C2(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)

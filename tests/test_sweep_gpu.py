@@ -82,7 +82,7 @@ def test_two_sweeps_in_a_row_deterministic(hip):
 
 # matrix-core kernel, explicit geometries -1,T,S,KW4 (T tiles of 16 responses per workgroup,
 # S waves, KW4 16-row tiles per wave): ragged rows / responses / last block of the sweep
-MFMA_GEOMS = ([f"-1,1,1,{kt}" for kt in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 18, 21)]
+MFMA_GEOMS = ([f"-1,1,1,{kt}" for kt in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 21)]
               + [f"-1,1,2,{kt}" for kt in range(1, 12)]          # rows cut over 2 workgroups
               + [f"-1,2,8,{kt}" for kt in range(1, 12)] + ["-1,1,1,0", "-1,1,2,0", "-1,1,0,0", "-1,2,8,0"])
 
