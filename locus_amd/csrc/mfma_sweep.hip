@@ -9,7 +9,6 @@
 
 namespace locus {
 
-int launch_mfma_sweep_t1(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
 int launch_mfma_sweep_t2(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
 int launch_mfma_sweep1_c1(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
 int launch_mfma_sweep1_c2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
@@ -325,10 +324,11 @@ static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, i
     const long n_wg = ((long)(k_end - k_begin) + 16L * T - 1) / (16L * T);
     dim3 grid((unsigned)n_wg), block((unsigned)(64 * (MW + 1)));
     const size_t lds = mfma_lds_bytes(T);
-    switch (T) {
-        case 1: return launch_mfma_sweep_t1(mp, KT, grid, block, lds, st);
-        default: return launch_mfma_sweep_t2(mp, KT, grid, block, lds, st);
+    if (T != 2) {
+        set_error("mfma sweep: mfma_sweep_kernel is instantiated for T = 2 only");
+        return LOCUS_HIP_EINVAL;
     }
+    return launch_mfma_sweep_t2(mp, KT, grid, block, lds, st);
 }
 
 // One launch sequence of mfma_sweep1_kernel over responses [k_begin, k_end): packs (if `pack`) and
@@ -440,8 +440,7 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
         set_error("mfma sweep: bad geometry (T in 0..2)");
         return LOCUS_HIP_EINVAL;
     }
-    const bool old1 = getenv("LOCUS_HIP_MFMA_OLD") != nullptr;  // A/B: round-1 T = 1 kernel
-    if (cfg.C == 1 && !old1) {  // one tile per cluster: mfma_sweep1_kernel, S = workgroups per cluster
+    if (cfg.C == 1) {  // one tile per cluster: mfma_sweep1_kernel, S = workgroups per cluster
         // S = workgroups per cluster (1, 2); 0 = chosen from d; anything else (legacy) = 1
         const int CS = (cfg.S == 2) ? 2 : (cfg.S == 0 ? choose_cs(prm.n, (prm.d + 15) / 16) : 1);
         const int KT = cfg.G > 0 ? cfg.G : mfma1_kt_for(prm.n, CS);
@@ -464,8 +463,8 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
         const int T = (kt2 > 0 && rem > cap1) ? 2 : 1;
         const int take = std::min(rem, T == 2 ? cap2 : cap1);
         int rc;
-        if (T == 2 || old1) {
-            rc = pack_and_launch(prm, T, T == 2 ? kt2 : kt1, k, k + take, T != last_T, xb_ws, xb_bytes, st);
+        if (T == 2) {
+            rc = pack_and_launch(prm, 2, kt2, k, k + take, T != last_T, xb_ws, xb_bytes, st);
         } else {
             const int CS = choose_cs(prm.n, (take + 15) / 16);
             rc = pack_and_launch1(prm, CS, mfma1_kt_for(prm.n, CS), k, k + take, true, xb_ws, xb_bytes,

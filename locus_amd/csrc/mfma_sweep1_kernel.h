@@ -401,12 +401,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     const double dot = fma(xtx, bo_c, u);
                     const double m = c_scale * dot;                            // coreLoop.cpp:42-43
                     const double a = cfac * ((lod - m * m * c_hinv) + c_cst);  // :45-46
-#if defined(EXP_NOCHAIN)
-                    const double e = a; const double gmv = 0.25 * e;
-#else
                     const double e = exp_nonpos(-fabs(a));
                     const double gmv = div_1to2((a >= 0.0) ? e : 1.0, 1.0 + e);
-#endif
                     const double bn = m * gmv;                                 // :48
                     // inactive steps / responses: beta_old is staged as 0 and every operand of m
                     // is 0, so delta = 0 without a select
