@@ -208,6 +208,10 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
     prm.state = a->state;
     prm.st = a->stats;
     if (cfg.NPL == -2) return run_stream_sweep(prm, logit != 0, st);
+    if (cfg.NPL == -3) {
+        LOCUS_REQUIRE(logit, "sweep: the look-ahead kernel {-3, ..} covers the logit family only");
+        return run_logit_la_sweep(prm, cfg, st);
+    }
     if (cfg.NPL < 0) {
         LOCUS_REQUIRE(!logit, "sweep: the matrix-core kernel covers the identity family only");
         return run_mfma_sweep(prm, cfg, ws.xb, mfma_workspace_bytes(a->n, a->p), st);

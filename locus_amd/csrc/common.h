@@ -95,5 +95,10 @@ int launch_sweep(const SweepParams& prm, const SweepConfig& cfg, bool logit, hip
 // chooser falls back to when n exceeds the register-resident kernels.
 int run_stream_sweep(const SweepParams& prm, bool logit, hipStream_t stream);
 size_t sweep_lds_bytes(const SweepConfig& cfg);
+// NPL == -3 selects the logit look-ahead kernel (logit_la.hip): latency regime of the logit family
+// (one workgroup per CU); then C = responses per workgroup (1, 2, 4; 0 = from d), G = rows per
+// lane (0 = smallest instantiated value that covers n).
+int logit_la_max_cr(int n);  // largest C for n rows; 0 = n not covered (n > 3072)
+int run_logit_la_sweep(const SweepParams& prm, const SweepConfig& cfg, hipStream_t stream);
 
 }  // namespace locus

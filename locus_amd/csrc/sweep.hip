@@ -84,7 +84,7 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
     if (const char* env = getenv("LOCUS_HIP_SWEEP_CFG")) {  // "NPL,C,S,G" (tuning / tests)
         SweepConfig c{};
         if (sscanf(env, "%d,%d,%d,%d", &c.NPL, &c.C, &c.S, &c.G) == 4 &&
-            (c.NPL == -2 || (c.NPL < 0 ? !logit : (c.NPL * c.S * 64 >= n)))) {
+            (c.NPL == -2 || (c.NPL == -3 ? logit : (c.NPL < 0 ? !logit : (c.NPL * c.S * 64 >= n))))) {
             *out = c;
             return 0;
         }
@@ -101,6 +101,16 @@ int choose_sweep_config(int n, int d, bool logit, SweepConfig* out)
     }
     const int units = (n + 63) / 64;  // 64-row units a column needs
     const int num_cu = device_cus();
+    // logit family, latency regime (at most one workgroup of 4 responses per CU): the look-ahead
+    // kernel with a dedicated chain wave.  LOCUS_HIP_SWEEP_VECTOR=1 keeps the vector kernel.
+    const int la_cr = logit ? logit_la_max_cr(n) : 0;
+    if (la_cr > 0 && (d + la_cr - 1) / la_cr <= num_cu) {
+        const char* v = getenv("LOCUS_HIP_SWEEP_VECTOR");
+        if (!(v && v[0] == '1')) {
+            *out = SweepConfig{-3, 0, 0, 0};  // C and G from (n, d) at launch
+            return 0;
+        }
+    }
     double best = 1e300;
     SweepConfig bc{0, 0, 0, 0};
     for (int npl : {2, 4, 8, 16}) {

@@ -34,8 +34,10 @@ def main():
     stats = torch.empty((4, d), device=dev, dtype=torch.float64)
     if logit:
         W2 = (torch.rand((d, n), device=dev, dtype=torch.float64, generator=g) * 0.2 + 0.2).t()
+        import os as _os
         s2 = torch.full((p, d), 1.0 / (n * 0.3), device=dev, dtype=torch.float64)
         xwx = torch.full((p, d), n * 0.3, device=dev, dtype=torch.float64)
+        ls2 = None if _os.environ.get('PERF_NO_LS2') else 0.5 * torch.log(s2)  # the driver tabulates it
     for cs in cfgs:
         cfg = None if cs == "auto" else tuple(map(int, cs.split(",")))
         sw = dv.Sweeper(px, d, dev, cfg=cfg)
@@ -46,7 +48,7 @@ def main():
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             if logit:
-                sw.logit(perm, lo, l1, s2, xwx, W2, 0.1, R, state, stats, nsteps)
+                sw.logit(perm, lo, l1, s2, xwx, W2, 0.1, R, state, stats, nsteps, ls2=ls2)
             else:
                 sw.identity(perm, lo, l1, scale, hinv, cst, s2k, 1.0, R, state, stats, nsteps)
             e1.record(); torch.cuda.synchronize()
@@ -56,7 +58,19 @@ def main():
         cfg_used = (_lib.ctypes.c_int32 * 4)()
         _lib.lib().locus_hip_sweep_config(n, d, int(logit), cfg_used)
         upd = nsteps * d / (t * 1e-3)
-        if "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0 and cfg[1] == 1:
+        if "diag" in _lib.LIB_PATH and cfg and cfg[0] == -3:
+            import ctypes
+            fn = ctypes.CDLL(_lib.LIB_PATH).locus_hip_diag_read_la_stamps
+            nwg = min(512, (d + max(cfg[1], 1) - 1) // max(cfg[1], 1))
+            buf = (ctypes.c_ulonglong * (24 * nwg))()
+            fn(buf, 24 * nwg)
+            a = np.array(buf, dtype=np.float64).reshape(nwg, 3, 8) / nsteps
+            for ro, nm, names in ((0, "vector wave 0", ["busy", "wait", "->update", "->reduce"]),
+                                  (2, "wave 6 (duties)", ["busy", "wait", "->stored", "->prepared"]),
+                                  (1, "chain", ["busy", "wait", "->U", "->delta"])):
+                med = np.median(a[:, ro, :len(names)], axis=0)
+                print(f"   ticks/step {nm:14s}: " + " ".join(f"{k}={v:.0f}" for k, v in zip(names, med)))
+        elif "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0 and cfg[1] == 1:
             import ctypes
             import os
             cs_used = 2 if (cfg[2] == 2 or os.environ.get("LOCUS_HIP_MFMA_CS") == "2") else 1

@@ -47,6 +47,12 @@ def test_geometry_chooser(n, d, logit, monkeypatch):
         assert list(cfg) == [-1, 0, 0, 0]
         monkeypatch.setenv("LOCUS_HIP_SWEEP_VECTOR", "1")
         _lib.check(_lib.lib().locus_hip_sweep_config(n, d, logit, cfg))
+    if logit and d <= 1024:
+        # logit family, at most one workgroup of 4 responses per CU (256 CUs assumed without a
+        # GPU): the look-ahead kernel, responses per workgroup and rows per lane set at launch
+        assert list(cfg) == [-3, 0, 0, 0]
+        monkeypatch.setenv("LOCUS_HIP_SWEEP_VECTOR", "1")
+        _lib.check(_lib.lib().locus_hip_sweep_config(n, d, logit, cfg))
     npl, c, s, g = list(cfg)
     assert npl in (2, 4, 8, 16) and 64 * npl * s >= n and 64 * s * g <= 1024
     assert 2 * npl * c * (2 if logit else 1) <= 170  # residual fits the 256-VGPR budget
@@ -54,12 +60,17 @@ def test_geometry_chooser(n, d, logit, monkeypatch):
 
 
 @pytest.mark.parametrize("n,logit", [(2049, 0), (2049, 1), (4096, 1), (4097, 0), (100000, 0)])
-def test_geometry_chooser_beyond_2048_rows(n, logit):
+def test_geometry_chooser_beyond_2048_rows(n, logit, monkeypatch):
     """2048 < n <= 4096: the wide vector instantiations (NPL = 16, S = 4, G = 2: 512 threads,
-    four staging pieces each); above: the streaming kernel, NPL = -2."""
+    four staging pieces each); above: the streaming kernel, NPL = -2.  (Logit with few responses
+    and n <= 3072: the look-ahead kernel first.)"""
     from locus_amd import _lib
     cfg = (ctypes.c_int32 * 4)()
     _lib.check(_lib.lib().locus_hip_sweep_config(n, 10, logit, cfg))
+    if logit and n <= 3072:
+        assert list(cfg) == [-3, 0, 0, 0]
+        monkeypatch.setenv("LOCUS_HIP_SWEEP_VECTOR", "1")
+        _lib.check(_lib.lib().locus_hip_sweep_config(n, 10, logit, cfg))
     if n <= 4096:
         assert list(cfg)[0] == 16 and list(cfg)[2:] == [4, 2] and cfg[1] <= (1 if logit else 4)
     else:

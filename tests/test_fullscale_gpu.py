@@ -167,6 +167,8 @@ def test_c4_logit_geometry_full_length(oracle, hip, monkeypatch):
     geometry the library picks for the full d = 500 (forced: at d = 8 it would pick another)."""
     from locus_amd import _lib
     cfg = _lib.sweep_config(2000, 500, logit=True)
+    if cfg[0] == -3:  # look-ahead kernel: responses per workgroup follow d at launch (500 -> 2)
+        cfg = (-3, 2, 0, 0)
     monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", ",".join(str(int(c)) for c in cfg))
     n, p, d = 2000, 20000, 8
     inp = inputs_for("logit", n, p, d, seed=4)

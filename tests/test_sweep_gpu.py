@@ -54,6 +54,35 @@ def test_sweep_geometries_logit(oracle, hip, geom, monkeypatch):
     assert_parity(got, ref, what=f"logit geom {geom}")
 
 
+# logit look-ahead kernel, explicit geometries -3,CR,-,NPL (CR responses per workgroup, six waves
+# of 64 NPL rows): ragged rows and responses, sweeps shorter and longer than the prefetch rings
+LA_GEOMS = [f"-3,{cr},0,{npl}" for npl in (1, 2, 3, 4, 5, 6, 8) for cr in (1, 2, 4)
+            if not (npl == 8 and cr == 4)] + ["-3,0,0,0"]
+
+
+@pytest.mark.parametrize("geom", LA_GEOMS)
+def test_logit_lookahead_geometries(oracle, hip, geom, monkeypatch):
+    _, cr, _, npl = map(int, geom.split(","))
+    n = 6 * 64 * npl - 5 if npl else 300
+    p, d = 29, 2 * max(cr, 1) + 1
+    inp = inputs_for("logit", n, p, d, seed=5)
+    ref = call_variant(oracle, "logit", inp)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", geom)
+    got = call_variant(hip, "logit", inp)
+    assert_parity(got, ref, what=f"logit look-ahead geom {geom}")
+
+
+@pytest.mark.parametrize("shape", [(100, 1, 3), (100, 2, 1), (64, 7, 9), (450, 8, 2), (449, 9, 5),
+                                   (1000, 203, 41)])
+def test_logit_lookahead_short_and_long_sweeps(oracle, hip, shape, monkeypatch):
+    n, p, d = shape
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", "-3,0,0,0")
+    inp = inputs_for("logit", n, p, d, seed=n + p)
+    ref = call_variant(oracle, "logit", inp)
+    got = call_variant(hip, "logit", inp)
+    assert_parity(got, ref, what=f"logit look-ahead {shape}")
+
+
 def test_annealing_factor(oracle, hip):
     inp = inputs_for("identity", 200, 60, 9, seed=3, c=0.37)
     ref = call_variant(oracle, "identity", inp)
