@@ -168,7 +168,7 @@ def main():
 
     from locus_amd import device as dv
     from locus_amd.comm import Comm, DistComm
-    from locus_amd.locus_core import IdentityEngine, IdentityHost
+    from locus_amd.locus_core import IdentityEngine, IdentityTail
     dv.require_gpu()
     if world > 1:
         import torch.distributed as dist
@@ -205,7 +205,7 @@ def main():
     state[0].uniform_(0, 1, generator=gen)                # gam ~ Beta(1, b) by inversion
     state[0] = -torch.expm1(torch.log1p(-state[0]) / b)
     state[1].normal_(0, 1, generator=gen)                 # mu ~ N(0, 1)
-    host = IdentityHost(n, p, d, hyper, tau0, sig2_beta0, comm)
+    host = IdentityTail(n, p, d, hyper, tau0, sig2_beta0, comm)
     eng = IdentityEngine(px, Y_dev, state, host, device)
     eng.initialise()
 
@@ -217,7 +217,7 @@ def main():
         nxt.append(torch.from_numpy(perm_rng.permutation(p).astype(np.float64)).to(device))
 
     def step():                                           # every step sweeps in a fresh random order
-        return eng.iterate(nxt.pop(0), 1.0, with_elbo=True, after_launch=draw_next)
+        return eng.iterate(nxt.pop(0), 1.0, with_elbo=True, after_launch=draw_next, c_next=1.0)
 
     # kernel timing: HIP events around the sweep launch, on the stream it is launched on
     orig_identity = eng.sweeper.identity

@@ -226,6 +226,180 @@ class IdentityHost(HostBase):
                      + e_om)
 
 
+class IdentityTail(IdentityHost):
+    """IdentityHost with every vector and scalar of the iteration held as a tensor on the device of
+    rowSums(gam) (the GPU; CPU tensors under the CPU test backend): the O(d_loc) updates
+    (R/locus_core.R:57-84), the packed all-reduce and the ELBO (:261-292, R/elbo.R) are queued
+    behind the sweep without a host round trip.  An iteration costs no H2D copy and ONE
+    device-to-host read, of the ELBO (none while annealing).  Same interface as IdentityHost;
+    begin_iteration returns device tensors and end_iteration takes them."""
+
+    device_resident = True
+
+    def _t(self, a, dev):
+        import torch
+        return torch.from_numpy(np.array(a, dtype=np.float64, copy=True)).to(dev)
+
+    def _to_device(self, dev):
+        import math
+
+        import torch
+        if getattr(self, "_dev", None) == dev:
+            return
+        self._dev = dev
+        self.a_t, self.b_t = self._t(self.a, dev), self._t(self.b, dev)
+        self.eta_t = self._t(np.broadcast_to(self.eta, self.tau_vb_init.shape), dev)
+        self.kappa_t = self._t(np.broadcast_to(self.kappa, self.tau_vb_init.shape), dev)
+        self.tau_t = self._t(self.tau_vb_init, dev)
+        self.s2_t = self._t(self.s2_init, dev)
+        # constants of e_tau_ / e_sig2_inv_ / e_omega_ (R/elbo.R:114-143)
+        self._e_tau_const = (self.eta_t * torch.log(self.kappa_t) - torch.lgamma(self.eta_t)).sum()
+        self._e_si_const = self.lam * math.log(self.nu) - math.lgamma(self.lam)
+        self._lbeta_ab = (torch.lgamma(self.a_t) + torch.lgamma(self.b_t)
+                          - torch.lgamma(self.a_t + self.b_t)).sum()
+        self._digam_sum = {}
+
+    def __init__(self, n, p, d_total, hyper, tau_vb, sig2_beta_vb, comm=None):
+        super().__init__(n, p, d_total, hyper, tau_vb, sig2_beta_vb, comm)
+        self.tau_vb_init = np.array(tau_vb, dtype=np.float64).reshape(-1)
+        self.s2_init = np.broadcast_to(np.asarray(sig2_beta_vb, dtype=np.float64),
+                                       self.tau_vb_init.shape).copy()
+        self.si_t = self.sum_gam_t = self.sum_tau_m2_t = self.stats_t = None
+
+    # host views of the device-resident quantities (outputs, R/locus_core.R:242-252)
+    tau_vb = property(lambda self: self.tau_t.cpu().numpy() if getattr(self, "tau_t", None)
+                      is not None else self.tau_vb_init, lambda self, v: None)
+    sig2_beta_vb = property(lambda self: self.s2_t.cpu().numpy() if getattr(self, "s2_t", None)
+                            is not None else self.s2_init, lambda self, v: None)
+    sig2_inv_vb = property(lambda self: None if self.si_t is None else float(self.si_t),
+                           lambda self, v: None)
+    sum_gam = property(lambda self: None if self.sum_gam_t is None else float(self.sum_gam_t),
+                       lambda self, v: None)
+    sum_tau_m2 = property(lambda self: None if self.sum_tau_m2_t is None
+                          else float(self.sum_tau_m2_t), lambda self, v: None)
+
+    def _reduce_t(self, rs_gam_local, scalars_t):
+        """ONE all-reduce of [rowSums(gam) (p) | scalars]; everything stays on the device."""
+        import torch
+        if self.comm.world == 1:
+            self.rs_gam_t = rs_gam_local.reshape(-1)
+            out = scalars_t
+        else:
+            buf = torch.cat([rs_gam_local.reshape(-1), scalars_t.reshape(-1)])
+            self.comm.all_reduce_sum_(buf)
+            self.rs_gam_t, out = buf[: self.p], buf[self.p:]
+        self.sum_gam_t = self.rs_gam_t.sum()
+        return out
+
+    def set_initial(self, stats, rs_gam_local):
+        import torch
+        self._to_device(rs_gam_local.device)
+        self.stats_t = torch.as_tensor(stats, dtype=torch.float64).to(self._dev)
+        sc = self._reduce_t(rs_gam_local, (self.tau_t @ self.stats_t[1]).reshape(1))
+        self.sum_tau_m2_t = sc[0]
+
+    def _lambda_nu(self, c=1.0):
+        lambda_vb = c * (self.lam + self.sum_gam_t / 2) - c + 1          # R/update_vb.R:198
+        nu_vb = c * (self.nu + self.sum_tau_m2_t / 2)                    # :204
+        return lambda_vb, nu_vb
+
+    def _eta_kappa(self, si, c=1.0):
+        n = self.n
+        cs_gam, cs_m2, cs_b2, rss = self.stats_t
+        eta_vb = c * (self.eta_t + n / 2 + cs_gam / 2) - c + 1           # :220
+        kappa_vb = c * (self.kappa_t + (rss + (n - 1 + si) * cs_m2 - (n - 1) * cs_b2) / 2)  # :229-237
+        return eta_vb, kappa_vb
+
+    def prepare_iteration(self, c=1.0):
+        """The updates at the top of an iteration (R/locus_core.R:57-84) from the statistics of
+        the last sweep, WITHOUT making them the host's current tau_vb / sig2_beta_vb /
+        sig2_inv_vb: the engine queues this behind the ELBO of the previous iteration, before it
+        knows whether another iteration follows, and commits it when one does."""
+        import torch
+        n = self.n
+        lambda_vb, nu_vb = self._lambda_nu(c)
+        si = lambda_vb / nu_vb
+        eta_vb, kappa_vb = self._eta_kappa(si, c)
+        tau = eta_vb / kappa_vb
+        s2 = 1 / (c * (n - 1 + si) * tau)                                 # :93-104
+        log_tau_vb = torch.digamma(eta_vb) - torch.log(kappa_vb)          # :275
+        log_sig2_inv_vb = torch.digamma(lambda_vb) - torch.log(nu_vb)     # :213
+        lo, l1 = self._log_om_terms(c)
+        return dict(lo=lo, l1=l1, log_sig2_inv_vb=log_sig2_inv_vb, log_tau_vb=log_tau_vb,
+                    tau_vb=tau, sig2_beta_vb=s2, sig2_inv_vb=si, c=float(c),
+                    # per-response constants of the sweep kernel (src/coreLoop.cpp:34,42)
+                    scale=c * s2 * tau, hinv=1.0 / (2.0 * s2),
+                    cst=-(log_tau_vb + log_sig2_inv_vb + torch.log(s2)) / 2, s2k=s2)
+
+    def commit_iteration(self, prm):
+        self.tau_t, self.s2_t, self.si_t = prm["tau_vb"], prm["sig2_beta_vb"], prm["sig2_inv_vb"]
+        return prm
+
+    def begin_iteration(self, c=1.0):                                     # R/locus_core.R:57-84
+        return self.commit_iteration(self.prepare_iteration(c))
+
+    def end_iteration(self, stats, rs_gam_local, ent_local, c=1.0, with_elbo=True, sync=True):
+        """sync=False returns the ELBO as a 0-dim device tensor (nothing waits for the GPU)."""
+        import math
+
+        import torch
+        n, d = self.n, self.d
+        self.stats_t = stats if torch.is_tensor(stats) else self._t(stats, self._dev)
+        ent = ent_local if torch.is_tensor(ent_local) else torch.tensor(
+            float(ent_local), dtype=torch.float64, device=self._dev)
+        self._last = (rs_gam_local, ent)
+        cs_gam, cs_m2, cs_b2, rss = self.stats_t
+        tau, s2, si = self.tau_t, self.s2_t, self.si_t
+        parts = [(tau @ cs_m2).reshape(1)]
+        if with_elbo:                                                    # R/elbo.R, summed over k
+            eta_vb, kappa_vb = self._eta_kappa(si)
+            log_tau_vb = torch.digamma(eta_vb) - torch.log(kappa_vb)
+            e_y = (-n / 2 * math.log(2 * math.pi) + n / 2 * log_tau_vb
+                   - tau * (kappa_vb - cs_m2 * si / 2 - self.kappa_t)).sum()          # :189-200
+            e_bg = (cs_gam * log_tau_vb / 2 - cs_m2 * tau * si / 2
+                    + cs_gam * (torch.log(s2) + 1) / 2).sum() - ent.reshape(())       # :43-54
+            e_tau = ((self.eta_t - eta_vb) * log_tau_vb - (self.kappa_t - kappa_vb) * tau
+                     - eta_vb * torch.log(kappa_vb) + torch.lgamma(eta_vb)).sum() \
+                + self._e_tau_const                                                  # :138-143
+            parts.append((e_y + e_bg + e_tau).reshape(1))
+        sc = self._reduce_t(rs_gam_local, torch.cat(parts))
+        self.sum_tau_m2_t = sc[0]
+        self._c_last = c
+        if not with_elbo:
+            return None
+        s_bg, e_om = self._omega_terms_t()                               # :270-275
+        lambda_vb, nu_vb = self._lambda_nu()
+        log_sig2_inv_vb = torch.digamma(lambda_vb) - torch.log(nu_vb)
+        e_si = ((self.lam - lambda_vb) * log_sig2_inv_vb - (self.nu - nu_vb) * si
+                - lambda_vb * torch.log(nu_vb) + torch.lgamma(lambda_vb)) + self._e_si_const  # :125-130
+        lb = sc[1] + log_sig2_inv_vb * self.sum_gam_t / 2 + s_bg + e_si + e_om
+        return float(lb) if sync else lb                                 # the iteration's one D2H
+
+    def held_out_elbo_(self, n_test, rss_test):
+        n_fit, st_fit = self.n, self.stats_t
+        try:
+            self.n = int(n_test)
+            st = st_fit.clone()
+            st[3] = self._t(rss_test, self._dev)
+            return self.end_iteration(st, *self._last)
+        finally:
+            self.n, self.stats_t = n_fit, st_fit
+
+    def _omega_terms_t(self):
+        import torch
+        d = self.d
+        rs, a, b = self.rs_gam_t, self.a_t, self.b_t
+        a_vb = a + rs                                    # update_a_vb / update_b_vb with c = 1
+        b_vb = b - rs + d
+        dg = torch.digamma(a_vb + b_vb)
+        log_om_vb = torch.digamma(a_vb) - dg
+        log_1_min_om_vb = torch.digamma(b_vb) - dg
+        s_bg = (rs * log_om_vb).sum() + ((d - rs) * log_1_min_om_vb).sum()
+        e_om = ((a - a_vb) * log_om_vb + (b - b_vb) * log_1_min_om_vb + torch.lgamma(a_vb)
+                + torch.lgamma(b_vb) - torch.lgamma(a_vb + b_vb)).sum() - self._lbeta_ab
+        return s_bg, e_om
+
+
 class IdentityEngine:
     """One GPU's shard of the identity-link model."""
 
@@ -274,15 +448,25 @@ class IdentityEngine:
         del M
         rss = (self.R * self.R).sum(dim=0)
         rs_gam, _ = dv.gamma_rows(self.state[0], p, d)
-        stats = t.cat([cols, rss.reshape(1, d)], dim=0).cpu().numpy()
+        stats = t.cat([cols, rss.reshape(1, d)], dim=0)
+        if not getattr(self.host, "device_resident", False):
+            stats = stats.cpu().numpy()
         self.host.set_initial(stats, rs_gam)
 
-    def iterate(self, shuffled_ind, c=1.0, with_elbo=True, after_launch=None):
+    def iterate(self, shuffled_ind, c=1.0, with_elbo=True, after_launch=None, c_next=None):
         """One pass of the loop body R/locus_core.R:49-211; returns the ELBO (or None).
         `after_launch()` runs on the host once the kernels of this iteration are queued and before
-        the host waits for their statistics (e.g. drawing the next sweep order)."""
+        the host waits for their statistics (e.g. drawing the next sweep order).  `c_next`
+        (device-resident host side only): annealing factor of the iteration that would follow;
+        its top-of-iteration updates are then queued before the host waits for this ELBO."""
         dv = self.dv
-        prm = self.host.begin_iteration(c)
+        resident = getattr(self.host, "device_resident", False)
+        nxt = getattr(self, "_prm_next", None)
+        self._prm_next = None
+        if resident and nxt is not None and nxt["c"] == float(c):
+            prm = self.host.commit_iteration(nxt)
+        else:
+            prm = self.host.begin_iteration(c)
         ind = shuffled_ind if self.torch.is_tensor(shuffled_ind) else self._up(shuffled_ind)
         self.sweeper.identity(ind, self._up(prm["lo"]), self._up(prm["l1"]),
                               self._up(prm["scale"]), self._up(prm["hinv"]), self._up(prm["cst"]),
@@ -291,6 +475,15 @@ class IdentityEngine:
                                     eps=self.host.ent_eps if with_elbo else None)
         tail = ent.sum().reshape(1) if with_elbo else self.torch.zeros(1, dtype=self.torch.float64,
                                                                       device=self.device)
+        if resident:
+            # everything after the sweep is queued on the device; the ELBO is the one read-back
+            lb = self.host.end_iteration(self.stats, rs_gam, tail, c, with_elbo, sync=False)
+            if c_next is not None:
+                self._prm_next = self.host.prepare_iteration(c_next)
+            if after_launch is not None:
+                after_launch()
+            self.sweeper.status()
+            return None if lb is None else float(lb)
         packed = self.torch.cat([self.stats.reshape(-1), tail])
         if after_launch is not None:
             after_launch()
@@ -374,7 +567,7 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
                                        (d,))[k_lo:k_hi]
     hyper_loc["kappa"] = np.broadcast_to(np.asarray(list_hyper["kappa"], dtype=np.float64),
                                          (d,))[k_lo:k_hi]
-    host = IdentityHost(n, p, d, hyper_loc, np.asarray(tau_vb)[k_lo:k_hi],
+    host = IdentityTail(n, p, d, hyper_loc, np.asarray(tau_vb)[k_lo:k_hi],
                         np.asarray(sig2_beta_vb)[k_lo:k_hi], comm)
     px = dv.PackedX(dv.to_device_colmajor(X, device))
     Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
@@ -402,9 +595,11 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
         def draw_next(it=it):                                            # overlaps the sweep
             if it < maxit:
                 nxt[it + 1] = np.ascontiguousarray(perm_fn(it + 1), dtype=np.float64)
-        lb = eng.iterate(ind, c, with_elbo=not annealing, after_launch=draw_next)
+        c_next = (float(ladder[it]) if it < len(ladder) else 1.0) if annealing else 1.0
+        lb = eng.iterate(ind, c, with_elbo=not annealing, after_launch=draw_next,
+                         c_next=c_next if it < maxit else None)
         if annealing:                                                    # :177-190
-            c = float(ladder[it]) if it < len(ladder) else 1.0
+            c = c_next
             if np.isclose(c, 1.0, rtol=1.5e-8, atol=0):
                 annealing = False
         else:

@@ -1,12 +1,16 @@
 """Wall-clock breakdown of one CAVI iteration of the identity driver (bench workload by default).
-usage: python scripts/step_breakdown.py [n p d]"""
-import sys, time
+usage: python scripts/step_breakdown.py [n p d]
+env: STEP_HOST=host uses the numpy host side (IdentityHost) instead of the device-resident tail;
+     STEP_SYNC=0 times whole iterations only (no synchronisation around the parts)."""
+import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 import bench
 from locus_amd import device as dv
 from locus_amd.comm import Comm
-from locus_amd.locus_core import IdentityEngine, IdentityHost
+from locus_amd.locus_core import IdentityEngine, IdentityHost, IdentityTail
+HostCls = IdentityHost if os.environ.get('STEP_HOST') == 'host' else IdentityTail
+SYNC = os.environ.get('STEP_SYNC', '1') != '0'
 
 n, p, d = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (1000, 50000, 10000)
 dev = torch.device("cuda:0")
@@ -19,7 +23,7 @@ hyper["lambda"] = 1e-2
 tau0 = np.full(d, 1 / med)
 state = torch.empty((3, p, d), dtype=torch.float64, device=dev)
 state[0].uniform_(0, 1e-3); state[1].normal_(0, 1)
-host = IdentityHost(n, p, d, hyper, tau0, 1.0 / np.random.default_rng(1).gamma(2.0, 1e-2 * tau0), Comm())
+host = HostCls(n, p, d, hyper, tau0, 1.0 / np.random.default_rng(1).gamma(2.0, 1e-2 * tau0), Comm())
 eng = IdentityEngine(px, Y, state, host, dev)
 eng.initialise()
 T = {}
@@ -32,14 +36,19 @@ def timed(obj, name, sync=True):
         T[name] = T.get(name, 0.0) + time.perf_counter() - t0
         return r
     setattr(obj, name, g)
-timed(host, "begin_iteration"); timed(host, "end_iteration"); timed(eng.sweeper, "identity")
-timed(dv, "gamma_rows"); timed(eng, "_up")
+if SYNC:
+    timed(host, "begin_iteration"); timed(host, "end_iteration"); timed(eng.sweeper, "identity")
+    timed(dv, "gamma_rows"); timed(eng, "_up")
 rng = np.random.default_rng(1)
 K = 6
 for it in range(K + 1):
     if it == 1:
         T.clear(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    tp = time.perf_counter(); ind = rng.permutation(p).astype(np.float64); T["perm"] = T.get("perm", 0) + time.perf_counter() - tp
-    eng.iterate(ind, 1.0, with_elbo=True)
+    if it == 0:
+        nxt = [rng.permutation(p).astype(np.float64)]
+    def draw():  # overlaps the sweep, as in locus_core_
+        tp = time.perf_counter(); nxt.append(rng.permutation(p).astype(np.float64)); T["perm"] = T.get("perm", 0) + time.perf_counter() - tp
+    kw = dict(c_next=1.0) if HostCls is IdentityTail else {}
+    eng.iterate(nxt.pop(0), 1.0, with_elbo=True, after_launch=draw, **kw)
 torch.cuda.synchronize(); tot = (time.perf_counter() - t0) / K
-print(f"total {tot*1e3:.2f} ms/iteration; " + " ".join(f"{k}={v/K*1e3:.2f}" for k, v in T.items()))
+print(f"{HostCls.__name__} n={n} p={p} d={d}: total {tot*1e3:.3f} ms/iteration; " + " ".join(f"{k}={v/K*1e3:.2f}" for k, v in T.items()))
