@@ -142,7 +142,8 @@ def committed_traffic(n, p, d_loc):
             if f.startswith("traffic_") and f.endswith(".json"):
                 try:
                     for rec in json.load(open(os.path.join(pdir, f))):
-                        if (rec["n"], rec["p"], rec["d_loc"]) == (n, p, d_loc):
+                        if ((rec.get("n"), rec.get("p"), rec.get("d_loc")) == (n, p, d_loc)
+                                and "hbm_bytes_per_launch" in rec):
                             best = rec["hbm_bytes_per_launch"]
                 except Exception:
                     pass

@@ -195,12 +195,18 @@ def locus_struct_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_v
     eng.initialise()
 
     converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
+    nxt = {}
     while (not converged) and it < maxit:                                # :51
         lb_old = lb_new
         it += 1
         if verbose and (it == 1 or it % 5 == 0):
             print(f"Iteration {it}... ")
-        lb_new = eng.iterate(np.ascontiguousarray(perm_fn(it), dtype=np.float64), 1.0)
+        ind = nxt.pop(it) if it in nxt else np.ascontiguousarray(perm_fn(it), dtype=np.float64)
+
+        def draw_next(it=it):                                            # overlaps the sweep
+            if it < maxit:
+                nxt[it + 1] = np.ascontiguousarray(perm_fn(it + 1), dtype=np.float64)
+        lb_new = eng.iterate(ind, 1.0, after_launch=draw_next)
         if trace is not None:
             trace.append((it, lb_new))
         if verbose and (it == 1 or it % 5 == 0):

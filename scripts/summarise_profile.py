@@ -25,12 +25,12 @@ lines = ["# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py 
 traffic = []
 # one sweep = the kernels locus_hip_sweep_dev launches; build_steps_kernel runs once per sweep
 nsweeps = max([len(v) for k, v in fetch.items() if "build_steps_kernel" in k] + [1])
-seq = [k for k in fetch if "mfma_sweep_kernel" in k or "pack_blocks_kernel" in k or
-       "sweep_kernel" in k or "build_steps_kernel" in k]
+SWEEP = ("sweep_kernel", "sweep1_kernel", "pack_blocks", "build_steps_kernel", "logit_la_kernel")
+seq = [k for k in fetch if any(s in k for s in SWEEP)]
 if seq:
     rd = sum(sum(fetch[k]) for k in seq) * 2 * 1024 / nsweeps
     wr = sum(sum(write.get(k, [0])) for k in seq) * 1024 / nsweeps
-    traffic.append(dict(n=n, p=p, d_loc=d_loc, kernel="sweep sequence: " + "; ".join(
+    traffic.append(dict(config="bench", n=n, p=p, d_loc=d_loc, kernel="sweep sequence: " + "; ".join(
                             f"{k[:60]} x{len(fetch[k]) / nsweeps:g}" for k in seq),
                         hbm_bytes_per_launch=rd + wr, hbm_read_bytes=rd, hbm_write_bytes=wr,
                         correction="2 x FETCH_SIZE (gfx950, 16-B coalesced loads) + WRITE_SIZE, "
@@ -39,8 +39,8 @@ for k in sorted(fetch, key=lambda k: -sum(fetch[k])):      # one row per kernel,
     fs = sum(fetch[k]) / len(fetch[k])
     ws = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
     lines.append(f"\"{k[:80]}\",{len(fetch[k])},{fs:.1f},{ws:.1f},{2*fs*1024:.4e},{ws*1024:.4e}")
-    if "sweep_kernel" in k:
-        traffic.append(dict(n=n, p=p, d_loc=d_loc, kernel=k, per="dispatch of this kernel",
+    if any(s in k for s in SWEEP[:2] + SWEEP[4:]):
+        traffic.append(dict(config="bench", n=n, p=p, d_loc=d_loc, kernel=k, per="dispatch of this kernel",
                             hbm_bytes_per_dispatch=2 * fs * 1024 + ws * 1024,
                             fetch_size_kib=fs, write_size_kib=ws,
                             correction="2 x FETCH_SIZE (gfx950, 16-B coalesced loads) + WRITE_SIZE"))
