@@ -17,7 +17,7 @@ import csv, glob, collections
 acc=collections.defaultdict(list)
 for f in glob.glob('gpurun_out/pmc/p*/**/*_counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'sweep_kernel' in r['Kernel_Name']:
+        if any(k in r['Kernel_Name'] for k in ('sweep_kernel', 'sweep1_kernel', 'logit_la_kernel')):
             acc[r['Counter_Name']].append((float(r['Counter_Value']), int(r['End_Timestamp'])-int(r['Start_Timestamp'])))
 for k,v in sorted(acc.items()):
     last=v[-1]
