@@ -47,6 +47,10 @@ struct GemmDesc {
     double* C; long sc_m, sc_n;
     double alpha, beta;
     int sqA, sqB;
+    // split-K launches (set by gemm_f64 itself): workgroup z covers k in [z kchunk, (z + 1) kchunk)
+    // and writes its partial product to C + z * cz
+    int kchunk = 0;
+    long cz = 0;
 };
 int gemm_f64(const GemmDesc& g, hipStream_t st);
 
