@@ -150,11 +150,16 @@ typedef struct locus_hip_sweep_args {
     int64_t workspace_bytes;
     int64_t nsteps;             /* covariates to visit (0 or p = full sweep)          */
     int32_t cfg[4];             /* NPL, C, S, G kernel geometry; all 0 = automatic;
-                                   NPL = -1: matrix-core kernel with C = tiles of 16 responses
-                                   per workgroup (1, 2; 0 = planned from d), S ignored,
-                                   G = 16-row tiles per matrix wave (0 = smallest that fits n);
+                                   NPL = -1: matrix-core kernel (identity family) with C = tiles
+                                   of 16 responses per workgroup (1, 2; 0 = planned from d);
+                                   C = 1: S = workgroups sharing the rows of a tile (1, 2;
+                                   0 = 2 when the tiles fit twice on the CUs); G = 16-row tiles
+                                   per matrix wave (0 = smallest that fits n);
                                    NPL = -2: streaming kernel (any n; what "automatic" picks
-                                   above 4096 rows), C, S, G ignored */
+                                   above 4096 rows), C, S, G ignored;
+                                   NPL = -3: logit look-ahead kernel, C = responses per
+                                   workgroup (1, 2, 4; 0 = from d), G = rows per lane of its
+                                   six row waves (1..6, 8; 0 = smallest that covers n <= 3072) */
     const double* ls2;          /* logit: [p][d] log(sig2_beta_vb) / 2 (locus_hip_half_log_dev),
                                    the last term of src/coreLoop.cpp:125 tabulated outside the
                                    latency-bound sweep; NULL = the kernel takes the logarithm */
@@ -177,9 +182,10 @@ int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream);
  * block-packed operand copies go to a fixed array of LOCUS_HIP_STATIC_WORKSPACE_BYTES that is
  * part of the library's code object (each GPU the library runs on holds it for the life of the
  * process).  Calls no hipMalloc / hipFree or allocating routine.  Limits: returns
- * LOCUS_HIP_EUNSUPPORTED when locus_hip_sweep_workspace_bytes(n, p) exceeds the array (n = 1000:
- * p <= ~3900 for the identity family, whose matrix-core kernel packs X per sweep; logit and
- * n > 2016 need ~28 p bytes: p up to ~2.3 million).  All calls on one GPU share that GPU's array:
+ * LOCUS_HIP_EUNSUPPORTED when locus_hip_sweep_workspace_bytes(n, p) exceeds the array.  For
+ * n <= 2016 that size covers the block-packed X operands and exchange buffers of the matrix-core
+ * sweep whatever the family: p <= 7248 at n = 200, 2528 at n = 1000, 1360 at n = 2000; above 2016
+ * rows only ~28 p bytes are needed (p up to ~2.3 million).  All calls on one GPU share that GPU's array:
  * two such sweeps that overlap on one GPU (different streams or threads) race -- serialise them.
  * Set-up: the first use on a device looks the array's address up (hipGetSymbolAddress; the HIP
  * runtime may materialise the array at that moment).  A caller that must not trigger even that
@@ -188,7 +194,8 @@ int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream);
 int locus_hip_sweep_static_dev(const locus_hip_sweep_args* args, int logit, void* stream);
 
 /* Geometry the library would pick for (n, d): fills cfg[4] = NPL, C, S, G
- * ({-1, 0, 0, 0}: the matrix-core sweep, launches planned from d; {-2, 0, 0, 0}: the
+ * ({-1, 0, 0, 0}: the matrix-core sweep, launches planned from d; {-3, 0, 0, 0}: the logit
+ * look-ahead kernel, responses per workgroup and rows per lane set at launch; {-2, 0, 0, 0}: the
  * streaming kernel, n > 4096). */
 int locus_hip_sweep_config(int64_t n, int64_t d, int logit, int32_t* cfg);
 
