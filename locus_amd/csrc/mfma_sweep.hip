@@ -50,8 +50,14 @@ pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ s
     const int rows_pad = NW * 16 * KT;
     const int NOP = 8 * KT;
     const int gt = tid >> 4, gs = tid & 15;
-    double gacc = 0.0;
-    double xacc[4] = {0.0, 0.0, 0.0, 0.0};  // lags 1 .. L-1 (L <= 5)
+    // Gram tiles X_b' X_{b-l}, l = 0 .. L-1, on the matrix cores: wave w contracts rows
+    // 32 w .. 32 w + 31 of every 128-row chunk (8 k-steps of v_mfma_f64_16x16x4_f64 per lag),
+    // the four partial tiles are added through LDS at the end
+    typedef double pk_d4 __attribute__((ext_vector_type(4)));
+    const int wv4 = tid >> 6, ln4 = tid & 63;
+    pk_d4 macc[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) macc[l] = (pk_d4){0.0, 0.0, 0.0, 0.0};
     __syncthreads();
     for (int c0 = 0; c0 < rows_pad; c0 += 128) {
         // all 8 L loads of this chunk are requested before the first one is used: a workgroup
@@ -99,19 +105,41 @@ pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ s
                     XS[(((size_t)wv * nit + b) * NOP + (oi & ~1)) * 64 + ln * 2 + (oi & 1)] = 0.0;
             }
         }
-#pragma unroll 4
-        for (int rr = 0; rr < 128; ++rr) {
-            const double a = xt[gt][rr];
-            gacc = fma(a, xt[gs][rr], gacc);
 #pragma unroll
-            for (int l = 1; l < L; ++l) xacc[l - 1] = fma(a, xl[16 * (l - 1) + gs][rr], xacc[l - 1]);
+        for (int q = 0; q < 8; ++q) {
+            // A[i = t][k = row] = X_b[row][t], B[k = row][j = s] = X_{b-l}[row][s]: both operands
+            // are read as [column = lane & 15][row = 4 (8 w + q) + (lane >> 4)]
+            const int rr = 4 * (8 * wv4 + q) + (ln4 >> 4);
+            const double a = xt[ln4 & 15][rr];
+            macc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, macc[0], 0, 0, 0);
+#pragma unroll
+            for (int l = 1; l < L; ++l)
+                macc[l] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xl[16 * (l - 1) + (ln4 & 15)][rr],
+                                                               macc[l], 0, 0, 0);
         }
     }
-    cg[(size_t)b * 256 + gs * 16 + gt] = (gt > gs) ? gacc : 0.0;
+    // D[t = (lane >> 4) + 4 r][s = lane & 15]: partial tiles of the four waves -> LDS -> one
+    // (t, s) pair per thread
+    __syncthreads();
+    double* red = pk_smem;  // [wave][l][r][lane], 4 L 256 doubles (the X tiles are dead)
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wv4 * L + l) * 4 + r) * 64 + ln4] = macc[l][r];
+    __syncthreads();
+    double gsum[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) a += red[((w * L + l) * 4 + (gt >> 2)) * 64 + (gt & 3) * 16 + gs];
+        gsum[l] = a;
+    }
+    cg[(size_t)b * 256 + gs * 16 + gt] = (gt > gs) ? gsum[0] : 0.0;
     // (X_b' X_{b-l})[t' = gt][s = gs]: A operand c = gs >> 2 of lane (gs & 3) * 16 + gt
 #pragma unroll
     for (int l = 1; l < L; ++l)
-        ax[((size_t)(l - 1) * (nit + 1) + b) * 256 + ((gs & 3) * 16 + gt) * 4 + (gs >> 2)] = xacc[l - 1];
+        ax[((size_t)(l - 1) * (nit + 1) + b) * 256 + ((gs & 3) * 16 + gt) * 4 + (gs >> 2)] = gsum[l];
 }
 
 // ---------------------------------------------------------------------------
