@@ -274,11 +274,54 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 for (int g = 0; g < 4; ++g) pb[g * 64] = acc[0][g] + acc[1][g];
             }
             if (xw) {
+                d4 xc;
+                const double* dp = dl + ((bx - 1) & (DR - 1)) * 256 + q * 16 + r;
+                const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
+                bool fast = false;
+                if constexpr (CS > 1) {
+                    // This wave usually gets here after everything it needs has been published
+                    // (its matrix work is the longest path of the iteration): read all flags, then
+                    // all data, in ONE batch of LDS requests -- the LDS unit serves a wave's requests
+                    // in order, so data read behind a flag that shows "published" is the published
+                    // data -- and fall back to waiting flag by flag when something is missing.
+                    int fl[L - 2];
+                    const int f_g = lds_peek(&gfin_ready);
+#pragma unroll
+                    for (int l = 2; l < L; ++l) fl[l - 2] = lds_peek(&cxf[l - 2]);
+                    const int f_p = lds_peek(&prog);
+                    asm volatile("" ::: "memory");
+                    double gq[4], cq[L - 2][4], b4[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gq[g] = gfin[g * 64 + lane];
+#pragma unroll
+                    for (int l = 2; l < L; ++l)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) cq[l - 2][g] = cx[(l - 2) * 256 + g * 64 + lane];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) b4[c] = dp[64 * c];
+                    asm volatile("" ::: "memory");
+                    fast = (f_g >= it) && (f_p >= 16 * bx);
+#pragma unroll
+                    for (int l = 2; l < L; ++l) fast = fast && (fl[l - 2] >= it);
+                    if (fast) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) xc[g] = gq[g];
+#pragma unroll
+                        for (int l = 2; l < L; ++l)   // same order of additions as the slow path
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) xc[g] += cq[l - 2][g];
+                        M1STAMP(2);
+                        M1STAMP(3);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], b4[c], xc, 0, 0, 0);
+                    }
+                }
+                if (!fast) {
                 for (int spin = 0; lds_peek(&gfin_ready) < it && spin < (1 << 22); ++spin)
                     __builtin_amdgcn_s_sleep(1);
                 asm volatile("" ::: "memory");
                 M1STAMP(2);
-                d4 xc;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) xc[g] = gfin[g * 64 + lane];
                 if constexpr (CS > 1) {
@@ -303,15 +346,26 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 }
                 M1STAMP(3);
                 // lag 1: the chain is producing these deltas right now
-                const double* dp = dl + ((bx - 1) & (DR - 1)) * 256 + q * 16 + r;
-                const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int target = 16 * (bx - 1) + 4 * c + 4;
-                    for (int spin = 0; lds_peek(&prog) < target && spin < (1 << 22); ++spin)
-                        __builtin_amdgcn_s_sleep(1);
+                if (lds_peek(&prog) >= 16 * bx) {
+                    // the chain has already finished block bx - 1 (this wave's matrix work took
+                    // longer): one batch of LDS reads, four MFMAs back to back
                     asm volatile("" ::: "memory");
-                    xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], dp[64 * c], xc, 0, 0, 0);
+                    double b4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) b4[c] = dp[64 * c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], b4[c], xc, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int target = 16 * (bx - 1) + 4 * c + 4;
+                        for (int spin = 0; lds_peek(&prog) < target && spin < (1 << 22); ++spin)
+                            __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+                        xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], dp[64 * c], xc, 0, 0, 0);
+                    }
+                }
                 }
                 double* go = gx + (bx & 1) * 256 + q * 16 + r;
 #pragma unroll
