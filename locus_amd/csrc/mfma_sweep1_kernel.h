@@ -217,17 +217,17 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             // helper); wave 0 adds them up and is left with lag 1, which follows the chain.
             const int bx = it - L + 2;
             const bool bx_ok = bx >= 0 && bx < P.nblk;
-            const bool xw = (m == 0) && bx_ok;
+            const bool xw = (CS == 1) && (m == 0) && bx_ok;  // clusters: the chain wave does it
             double2 axr[(CS > 1) ? 1 : L - 1][2];
             if constexpr (CS > 1) {
-                if (bx_ok && m <= L - 2) {
-                    // this wave's lag: m == 0 -> 1 (used at the end), m >= 1 -> m + 1 (used now)
-                    const int lagi = (m == 0) ? 0 : m;  // index l - 1
+                if (bx_ok && m >= 1 && m <= L - 2) {
+                    // this wave's lag: m + 1 (index l - 1 = m)
+                    const int lagi = m;
                     const double2* ap =
                         reinterpret_cast<const double2*>(axl + ((bx & 1) * (L - 1) + lagi) * 256) + 2 * lane;
                     axr[0][0] = ap[0];
                     axr[0][1] = ap[1];
-                    if (m >= 1) {
+                    {
                         const double* dp = dl + ((bx - (m + 1)) & (DR - 1)) * 256 + q * 16 + r;
                         const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
                         d4 cc = d4{0.0, 0.0, 0.0, 0.0};
@@ -277,47 +277,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 d4 xc;
                 const double* dp = dl + ((bx - 1) & (DR - 1)) * 256 + q * 16 + r;
                 const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
-                bool fast = false;
-                if constexpr (CS > 1) {
-                    // This wave usually gets here after everything it needs has been published
-                    // (its matrix work is the longest path of the iteration): read all flags, then
-                    // all data, in ONE batch of LDS requests -- the LDS unit serves a wave's requests
-                    // in order, so data read behind a flag that shows "published" is the published
-                    // data -- and fall back to waiting flag by flag when something is missing.
-                    int fl[L - 2];
-                    const int f_g = lds_peek(&gfin_ready);
-#pragma unroll
-                    for (int l = 2; l < L; ++l) fl[l - 2] = lds_peek(&cxf[l - 2]);
-                    const int f_p = lds_peek(&prog);
-                    asm volatile("" ::: "memory");
-                    double gq[4], cq[L - 2][4], b4[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) gq[g] = gfin[g * 64 + lane];
-#pragma unroll
-                    for (int l = 2; l < L; ++l)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) cq[l - 2][g] = cx[(l - 2) * 256 + g * 64 + lane];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) b4[c] = dp[64 * c];
-                    asm volatile("" ::: "memory");
-                    fast = (f_g >= it) && (f_p >= 16 * bx);
-#pragma unroll
-                    for (int l = 2; l < L; ++l) fast = fast && (fl[l - 2] >= it);
-                    if (fast) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) xc[g] = gq[g];
-#pragma unroll
-                        for (int l = 2; l < L; ++l)   // same order of additions as the slow path
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) xc[g] += cq[l - 2][g];
-                        M1STAMP(2);
-                        M1STAMP(3);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], b4[c], xc, 0, 0, 0);
-                    }
-                }
-                if (!fast) {
+                {
                 for (int spin = 0; lds_peek(&gfin_ready) < it && spin < (1 << 22); ++spin)
                     __builtin_amdgcn_s_sleep(1);
                 asm volatile("" ::: "memory");
@@ -415,8 +375,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             __syncthreads();  // B1
             M1STAMP(0);
             const int b = it - L + 1;  // block whose chain runs now
-            if (b < 0 || b >= P.nblk) continue;
-            if (lane < 16) {
+            if (b >= 0 && b < P.nblk && lane < 16) {
                 const double* gx_l = gx + (b & 1) * 256 + lane;
                 const double* bo_l = bol + (b & 1) * 256 + lane;
                 double* dl_w = dl + (b & (DR - 1)) * 256 + lane;
@@ -468,7 +427,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     dl_w[t * 16] = delta;
                     mg_w[t * 16] = m;
                     mg_w[256 + t * 16] = gmv;
-                    if constexpr ((t & 3) == 3) lds_publish(&prog, 16 * b + t + 1);
+                    if constexpr (CS == 1 && (t & 3) == 3) lds_publish(&prog, 16 * b + t + 1);
                     u_c = u_n;
                     bo_c = bo_n;
                     sc_c = sc_n;
@@ -476,6 +435,68 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 });
             }
             M1STAMP(1);
+            if constexpr (CS > 1) {
+                // Cross-block corrections of the block this wave runs NEXT (all 64 lanes):
+                //   gx = reduced G (helper) + sum_{l >= 2} (X_bx' X_{bx-l}) d_{bx-l} (matrix waves 1 ..
+                //        L-2, published long ago) + (X_bx' X_{bx-1}) d_{bx-1} (just produced here).
+                // On matrix wave 0, where this used to live, its ~60 VALU instructions crawled
+                // behind the fp64 MFMA stream of the other wave of the SIMD (an MFMA holds the VALU
+                // for 64 cycles) and ended every iteration ~2000 cycles after the chain; SIMD 3 runs
+                // no such stream, and nobody has to follow the chain's progress any more.
+                const int bx = b + 1;
+                if (bx >= 0 && bx < P.nblk) {
+                    int fl[L - 1];
+                    fl[0] = lds_peek(&gfin_ready);
+#pragma unroll
+                    for (int l = 2; l < L; ++l) fl[l - 1] = lds_peek(&cxf[l - 2]);
+                    asm volatile("" ::: "memory");  // flags first: the LDS serves a wave in order
+                    const double2* ap =
+                        reinterpret_cast<const double2*>(axl + ((bx & 1) * (L - 1)) * 256) + 2 * lane;
+                    const double2 a01 = ap[0], a23 = ap[1];
+                    const double* dp = dl + ((bx - 1) & (DR - 1)) * 256 + q * 16 + r;
+                    double b4[4], gq[4], cq[L - 2][4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) b4[c] = dp[64 * c];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gq[g] = gfin[g * 64 + lane];
+#pragma unroll
+                    for (int l = 2; l < L; ++l)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) cq[l - 2][g] = cx[(l - 2) * 256 + g * 64 + lane];
+                    asm volatile("" ::: "memory");
+                    bool ok = fl[0] >= it;
+#pragma unroll
+                    for (int l = 2; l < L; ++l) ok = ok && (fl[l - 1] >= it);
+                    if (!ok) {  // something was late: wait for it, read again
+                        for (int spin = 0; lds_peek(&gfin_ready) < it && spin < (1 << 22); ++spin)
+                            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int l = 2; l < L; ++l)
+                            for (int spin = 0; lds_peek(&cxf[l - 2]) < it && spin < (1 << 22); ++spin)
+                                __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) gq[g] = gfin[g * 64 + lane];
+#pragma unroll
+                        for (int l = 2; l < L; ++l)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) cq[l - 2][g] = cx[(l - 2) * 256 + g * 64 + lane];
+                    }
+                    d4 xc = d4{gq[0], gq[1], gq[2], gq[3]};
+#pragma unroll
+                    for (int l = 2; l < L; ++l)   // fixed order: identical sums in every member
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) xc[g] += cq[l - 2][g];
+                    const double axv[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], b4[c], xc, 0, 0, 0);
+                    double* go = gx + (bx & 1) * 256 + q * 16 + r;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) go[64 * g] = xc[g];
+                }
+            }
+            M1STAMP(3);
         }
         M1STAMP_FLUSH(2);
         __syncthreads();  // E1

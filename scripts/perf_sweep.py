@@ -82,7 +82,7 @@ def main():
             a = a[a[:, 2, 1] > 0] / ((nsteps + 15) // 16)
             roles = {0: ("matrix wave 0", ["B1-wait", "mfma", "gfin-wait", "corr(l>=2)", "follow+write"]),
                      1: ("matrix wave 5", ["B1-wait", "mfma"]),
-                     2: ("chain", ["B1-wait", "run"]),
+                     2: ("chain", ["B1-wait", "run", "-", "next-G"]),
                      3: ("helper", ["B1-wait", "reduce/xchg", "store/bol"])}
             for ro, (nm, names) in roles.items():
                 med = np.median(a[:, ro, :len(names)], axis=0)
