@@ -169,7 +169,7 @@ def main():
 
     from locus_amd import device as dv
     from locus_amd.comm import Comm, DistComm
-    from locus_amd.locus_core import IdentityEngine, IdentityTail
+    from locus_amd.locus_core import FusedTail, IdentityEngine
     dv.require_gpu()
     if world > 1:
         import torch.distributed as dist
@@ -206,7 +206,7 @@ def main():
     state[0].uniform_(0, 1, generator=gen)                # gam ~ Beta(1, b) by inversion
     state[0] = -torch.expm1(torch.log1p(-state[0]) / b)
     state[1].normal_(0, 1, generator=gen)                 # mu ~ N(0, 1)
-    host = IdentityTail(n, p, d, hyper, tau0, sig2_beta0, comm)
+    host = FusedTail(n, p, d, hyper, tau0, sig2_beta0, comm, dv=dv)
     eng = IdentityEngine(px, Y_dev, state, host, device)
     eng.initialise()
 

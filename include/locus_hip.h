@@ -291,6 +291,49 @@ int locus_hip_probit_w_dev(const double* Y, const double* M, const double* Zmu, 
                            const double* zs, double* W, double* ey, int64_t n, int64_t d,
                            void* stream);
 
+/* Iteration tail of locus_core_ on the device, on REDUCED statistics: the ELBO of the iteration
+ * that ended (elbo_, R/locus_core.R:261-292; e_y_, e_beta_gamma_, e_tau_, e_sig2_inv_, e_omega_ of
+ * R/elbo.R:43-54,114-143,189-200) and the updates at the top of the next one
+ * (R/locus_core.R:57-84; R/update_vb.R:181-237,275).  Two phases around the caller's all-reduce of
+ * [rowSums(gam_vb) | shard2] over the response shards:
+ *   phase 0 (after the sweep and gamma_rows): shard2[0] = sum_k tau_k colSums(m2_beta)_k,
+ *           shard2[1] = shard-local ELBO terms (0 unless with_elbo);
+ *   phase 1 (after the all-reduce): scal[0] = ELBO (with_elbo), scal[1] = sum(gam_vb),
+ *           scal[2] = sum_k tau_k colSums(m2_beta)_k, scal[4] / scal[5] = sig2_inv_vb /
+ *           log_sig2_inv_vb of the next iteration at annealing factor c_next; lo / l1 =
+ *           log_om_vb / log_1_min_om_vb, and tau_next, s2_next, scale, hinv, cst = tau_vb,
+ *           sig2_beta_vb and the per-response constants locus_hip_sweep_dev takes (NULL: skipped).
+ * *si_in is sig2_inv_vb of the iteration that ended (read by both phases; it may be scal[4] of
+ * the previous call's scal buffer). */
+typedef struct locus_hip_tail_args {
+    int64_t n, p, d_loc, d_total;
+    const double* a;            /* [p] hyper-parameters of omega                       */
+    const double* b;
+    const double* eta;          /* [d_loc] hyper-parameters of tau                     */
+    const double* kappa;
+    double lam, nu;             /* hyper-parameters of sig2_inv                        */
+    const double* stats;        /* [4][d_loc] column statistics of the sweep epilogue  */
+    const double* tau;          /* [d_loc] tau_vb the sweep used                       */
+    const double* s2;           /* [d_loc] sig2_beta_vb the sweep used                 */
+    const double* rs_gam;       /* [p] rowSums(gam_vb) over ALL shards (phase 1)       */
+    const double* ent;          /* [p] entropy partials of gamma_rows (phase 0) / NULL */
+    const double* si_in;        /* sig2_inv_vb the sweep used                          */
+    double* shard2;             /* [2] see above                                       */
+    double* scal;               /* [8] see above                                       */
+    int32_t with_elbo;
+    int32_t pad_;
+    double c_next;
+    double* lo;                 /* [p] or NULL                                         */
+    double* l1;
+    double* tau_next;           /* [d_loc] or NULL (then s2_next, scale, hinv, cst too) */
+    double* s2_next;
+    double* scale;
+    double* hinv;
+    double* cst;
+    double* part;               /* [192] scratch of phase 1                            */
+} locus_hip_tail_args;
+int locus_hip_identity_tail_dev(const locus_hip_tail_args* args, int phase, void* stream);
+
 /* Per-covariate sums over the local responses: rs_gam, entropy term (as gamma_rows),
  * gls[j] = sum_k gam log(s2), m2[j] = sum_k gam (mu^2 + s2): the O(p d) parts of
  * e_beta_gamma_bin_ (R/elbo.R:77-87) and update_nu_bin_vb_ (R/update_vb.R:210). */

@@ -39,6 +39,19 @@ class SweepArgs(ctypes.Structure):
     ]
 
 
+class TailArgs(ctypes.Structure):
+    """struct locus_hip_tail_args (include/locus_hip.h)."""
+    _fields_ = [
+        ("n", _i64), ("p", _i64), ("d_loc", _i64), ("d_total", _i64),
+        ("a", _ptr), ("b", _ptr), ("eta", _ptr), ("kappa", _ptr), ("lam", _dbl), ("nu", _dbl),
+        ("stats", _ptr), ("tau", _ptr), ("s2", _ptr), ("rs_gam", _ptr), ("ent", _ptr),
+        ("si_in", _ptr), ("shard2", _ptr), ("scal", _ptr),
+        ("with_elbo", ctypes.c_int32), ("pad_", ctypes.c_int32), ("c_next", _dbl),
+        ("lo", _ptr), ("l1", _ptr), ("tau_next", _ptr), ("s2_next", _ptr), ("scale", _ptr),
+        ("hinv", _ptr), ("cst", _ptr), ("part", _ptr),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/locus_hip.h declares
 _LOOP_COMMON = [_ptr] * 5 + [_dbl]
 SIGNATURES = {
@@ -83,6 +96,7 @@ SIGNATURES = {
     "locus_hip_logit_sig2_alpha_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr]),
     "locus_hip_alpha_step_dev": (_int, [_ptr] * 7 + [_i64, _i64, _ptr]),
     "locus_hip_probit_w_dev": (_int, [_ptr] * 7 + [_i64, _i64, _ptr]),
+    "locus_hip_identity_tail_dev": (_int, [ctypes.POINTER(TailArgs), _int, _ptr]),
     "locus_hip_bin_rows_dev": (_int, [_ptr, _ptr, _dbl, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _dbl,
                                       _ptr]),
     # resident context (host pointers)

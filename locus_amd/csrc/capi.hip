@@ -640,6 +640,24 @@ int locus_hip_transpose_dev(const double* in, double* out, int64_t rows, int64_t
     return transpose(in, out, (int)rows, (int)cols, (hipStream_t)stream);
 }
 
+int locus_hip_identity_tail_dev(const locus_hip_tail_args* a, int phase, void* stream)
+{
+    LOCUS_REQUIRE(a != nullptr && (phase == 0 || phase == 1), "identity_tail: bad arguments");
+    LOCUS_REQUIRE(a->n >= 1 && a->p >= 1 && a->d_loc >= 1 && a->d_total >= a->d_loc &&
+                      a->p < (1ll << 31) && a->d_loc < (1ll << 31),
+                  "identity_tail: bad dimensions");
+    LOCUS_REQUIRE(a->eta && a->kappa && a->stats && a->shard2 && a->scal && a->si_in,
+                  "identity_tail: NULL device pointer");
+    if (phase == 0)
+        LOCUS_REQUIRE(a->tau && a->s2, "identity_tail: phase 0 needs tau, s2");
+    else
+        LOCUS_REQUIRE(a->a && a->b && a->rs_gam && a->part && (a->lo == nullptr) == (a->l1 == nullptr) &&
+                          (a->tau_next == nullptr ||
+                           (a->s2_next && a->scale && a->hinv && a->cst)),
+                      "identity_tail: phase 1 needs a, b, rs_gam, part and complete output sets");
+    return identity_tail(*a, phase, (hipStream_t)stream);
+}
+
 int locus_hip_gamma_rows_dev(const double* gam, double* rs_gam, double* ent, int64_t p, int64_t d,
                              double eps, void* stream)
 {

@@ -53,5 +53,6 @@ struct GemmDesc {
     long cz = 0;
 };
 int gemm_f64(const GemmDesc& g, hipStream_t st);
+int identity_tail(const locus_hip_tail_args& a, int phase, hipStream_t st);
 
 }  // namespace locus

@@ -1,0 +1,229 @@
+// Iteration tail of the identity driver in three small kernels (locus_hip_identity_tail_dev).
+//
+// What the reference does between two sweeps of locus_core_ -- the ELBO of the iteration that
+// ended (elbo_, R/locus_core.R:261-292; e_y_, e_beta_gamma_, e_tau_, e_sig2_inv_, e_omega_ of
+// R/elbo.R) and the updates at the top of the next one (R/locus_core.R:57-84: lambda_vb, nu_vb,
+// sig2_inv_vb, eta_vb, kappa_vb, tau_vb, sig2_beta_vb, log_tau_vb, log_om_vb, log_1_min_om_vb) --
+// is O(p + d) arithmetic on REDUCED statistics (the sweep epilogue's column sums, gamma_rows' row
+// sums).  As ~150 tiny tensor kernels it cost 0.4 ms per iteration; here:
+//   phase 0  tail_resp_kernel   one workgroup over the d_loc responses: shard-local sums
+//                                [sum_k tau_k cs_m2_k | e_y_ + e_beta_gamma_ (k part) + e_tau_]
+//            -> the two scalars that ride in the all-reduce behind rowSums(gam)
+//   phase 1  tail_cov_kernel    64 workgroups over the p covariates: sum_j rs_gam, the covariate
+//                                terms of e_beta_gamma_ and e_omega_, log_om_vb / log_1_min_om_vb
+//            tail_final_kernel  one workgroup: the scalars (lambda, nu, sig2_inv, ELBO) and the
+//                                per-response constants of the next sweep
+// digamma follows the Cephes scheme (recurrence to x >= 10, 7-term asymptotic series); lgamma is
+// the device library's.
+#include "common.h"
+#include "kernels.h"
+
+namespace locus {
+namespace {
+
+constexpr int kCovBlocks = 64;
+
+__device__ __forceinline__ double digamma_pos(double x)
+{
+    double w = 0.0;
+    while (x < 10.0) {
+        w += 1.0 / x;
+        x += 1.0;
+    }
+    const double z = 1.0 / (x * x);
+    double y = 8.33333333333333333333e-2;
+    y = fma(y, z, -2.10927960927960927961e-2);
+    y = fma(y, z, 7.57575757575757575758e-3);
+    y = fma(y, z, -4.16666666666666666667e-3);
+    y = fma(y, z, 3.96825396825396825397e-3);
+    y = fma(y, z, -8.33333333333333333333e-3);
+    y = fma(y, z, 8.33333333333333333333e-2);
+    return log(x) - 0.5 / x - z * y - w;
+}
+
+// Sum of NV values per thread over a workgroup of 1024 threads (fixed order: deterministic).
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* red)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[i * nthr + tid] = v[i];
+    __syncthreads();
+    for (int s = nthr >> 1; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) red[i * nthr + tid] += red[i * nthr + tid + s];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = red[i * nthr];
+    __syncthreads();
+}
+
+// eta_vb, kappa_vb of response k at annealing factor c (R/update_vb.R:220, :229-237 on reduced
+// statistics: rss = colSums((Y - mat_x_m1)^2))
+__device__ __forceinline__ void eta_kappa(const locus_hip_tail_args& a, int k, double si, double c,
+                                          double* eta_vb, double* kappa_vb)
+{
+    const double n = (double)a.n;
+    const double cs_gam = a.stats[k], cs_m2 = a.stats[a.d_loc + k];
+    const double cs_b2 = a.stats[2 * a.d_loc + k], rss = a.stats[3 * a.d_loc + k];
+    *eta_vb = c * (a.eta[k] + n / 2 + cs_gam / 2) - c + 1;
+    *kappa_vb = c * (a.kappa[k] + (rss + (n - 1 + si) * cs_m2 - (n - 1) * cs_b2) / 2);
+}
+
+// ---- phase 0 ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) tail_resp_kernel(const locus_hip_tail_args a)
+{
+    __shared__ double red[2 * 1024];
+    const int tid = threadIdx.x;
+    const double si = *a.si_in;  // sig2_inv_vb of the iteration that ended
+    const double n = (double)a.n;
+    double v[2] = {0.0, 0.0};
+    for (int k = tid; k < a.d_loc; k += 1024) {
+        const double tau = a.tau[k], s2 = a.s2[k];
+        const double cs_gam = a.stats[k], cs_m2 = a.stats[a.d_loc + k];
+        v[0] += tau * cs_m2;                                        // crossprod(tau_vb, colSums(m2_beta))
+        if (a.with_elbo) {
+            double eta_vb, kappa_vb;
+            eta_kappa(a, k, si, 1.0, &eta_vb, &kappa_vb);
+            const double log_tau = digamma_pos(eta_vb) - log(kappa_vb);
+            // e_y_ (R/elbo.R:189-200)
+            double e = -n / 2 * 1.8378770664093453 + n / 2 * log_tau -
+                       tau * (kappa_vb - cs_m2 * si / 2 - a.kappa[k]);
+            // e_beta_gamma_, the terms swept by response (R/elbo.R:43-54)
+            e += cs_gam * log_tau / 2 - cs_m2 * tau * si / 2 + cs_gam * (log(s2) + 1) / 2;
+            // e_tau_ (R/elbo.R:138-143)
+            e += (a.eta[k] - eta_vb) * log_tau - (a.kappa[k] - kappa_vb) * tau +
+                 a.eta[k] * log(a.kappa[k]) - eta_vb * log(kappa_vb) - lgamma(a.eta[k]) +
+                 lgamma(eta_vb);
+            v[1] += e;
+        }
+    }
+    if (a.with_elbo && a.ent != nullptr)   // entropy term of e_beta_gamma_ (gamma_rows)
+        for (int j = tid; j < a.p; j += 1024) v[1] -= a.ent[j];
+    block_sum<2>(v, red);
+    if (tid == 0) {
+        a.shard2[0] = v[0];
+        a.shard2[1] = v[1];
+    }
+}
+
+// ---- phase 1 ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tail_cov_kernel(const locus_hip_tail_args a, double* part)
+{
+    __shared__ double red[3 * 256];
+    const int tid = threadIdx.x;
+    const double d = (double)a.d_total, c = a.c_next;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int j = blockIdx.x * 256 + tid; j < a.p; j += 256 * kCovBlocks) {
+        const double rs = a.rs_gam[j], av = a.a[j], bv = a.b[j];
+        v[0] += rs;
+        const double a_vb = av + rs, b_vb = bv - rs + d;          // update_a_vb / update_b_vb, c = 1
+        double lo1 = 0.0, l11 = 0.0;
+        if (a.with_elbo || c == 1.0) {
+            const double dg = digamma_pos(a_vb + b_vb);
+            lo1 = digamma_pos(a_vb) - dg;                           // R/update_vb.R:187,190
+            l11 = digamma_pos(b_vb) - dg;
+        }
+        if (a.with_elbo) {
+            v[1] += rs * lo1 + (d - rs) * l11;                      // e_beta_gamma_ (R/elbo.R:43-54)
+            v[2] += (av - a_vb) * lo1 + (bv - b_vb) * l11 -         // e_omega_ (R/elbo.R:114-118)
+                    (lgamma(av) + lgamma(bv) - lgamma(av + bv)) +
+                    (lgamma(a_vb) + lgamma(b_vb) - lgamma(a_vb + b_vb));
+        }
+        if (a.lo != nullptr) {   // log_om_vb, log_1_min_om_vb of the NEXT iteration (annealing c)
+            if (c == 1.0) {
+                a.lo[j] = lo1;
+                a.l1[j] = l11;
+            } else {
+                const double dgs = digamma_pos(c * (av + bv + d) - 2 * c + 2);
+                a.lo[j] = digamma_pos(c * a_vb - c + 1) - dgs;
+                a.l1[j] = digamma_pos(c * b_vb - c + 1) - dgs;
+            }
+        }
+    }
+    const int nthr = 256;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) red[i * nthr + tid] = v[i];
+    __syncthreads();
+    for (int s = nthr >> 1; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) red[i * nthr + tid] += red[i * nthr + tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid < 3) part[blockIdx.x * 3 + tid] = red[tid * nthr];
+}
+
+__global__ void __launch_bounds__(1024) tail_final_kernel(const locus_hip_tail_args a,
+                                                          const double* part)
+{
+    __shared__ double sh[4];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        double sum_gam = 0.0, s_bg = 0.0, e_om = 0.0;
+        for (int b = 0; b < kCovBlocks; ++b) {   // fixed order
+            sum_gam += part[3 * b];
+            s_bg += part[3 * b + 1];
+            e_om += part[3 * b + 2];
+        }
+        const double sum_tau_m2 = a.shard2[0];
+        const double si_old = *a.si_in;
+        if (a.with_elbo) {
+            // elbo_ (R/locus_core.R:261-292): NEW lambda / nu, the sig2_inv_vb the sweep used
+            const double lambda_vb = a.lam + sum_gam / 2;            // R/update_vb.R:198, c = 1
+            const double nu_vb = a.nu + sum_tau_m2 / 2;              // :204
+            const double log_si = digamma_pos(lambda_vb) - log(nu_vb);
+            const double e_si = (a.lam - lambda_vb) * log_si - (a.nu - nu_vb) * si_old +
+                                a.lam * log(a.nu) - lambda_vb * log(nu_vb) - lgamma(a.lam) +
+                                lgamma(lambda_vb);                   // e_sig2_inv_ (R/elbo.R:125-130)
+            a.scal[0] = a.shard2[1] + log_si * sum_gam / 2 + s_bg + e_si + e_om;
+        }
+        a.scal[1] = sum_gam;
+        a.scal[2] = sum_tau_m2;
+        // top of the next iteration (R/locus_core.R:57-62), annealing factor c_next
+        const double c = a.c_next;
+        const double lambda_n = c * (a.lam + sum_gam / 2) - c + 1;
+        const double nu_n = c * (a.nu + sum_tau_m2 / 2);
+        sh[0] = lambda_n / nu_n;
+        sh[1] = digamma_pos(lambda_n) - log(nu_n);                   // log_sig2_inv_vb (:213)
+        a.scal[4] = sh[0];                                           // sig2_inv_vb of the next iteration
+        a.scal[5] = sh[1];
+    }
+    __syncthreads();
+    if (a.tau_next == nullptr) return;
+    const double si = sh[0], log_si = sh[1], c = a.c_next, n = (double)a.n;
+    for (int k = tid; k < a.d_loc; k += 1024) {                      // R/locus_core.R:64-84
+        double eta_vb, kappa_vb;
+        eta_kappa(a, k, si, c, &eta_vb, &kappa_vb);
+        const double tau = eta_vb / kappa_vb;
+        const double s2 = 1 / (c * (n - 1 + si) * tau);              // R/update_vb.R:93-104
+        const double log_tau = digamma_pos(eta_vb) - log(kappa_vb);  // :275
+        a.tau_next[k] = tau;
+        a.s2_next[k] = s2;
+        // per-response constants of the sweep kernel (src/coreLoop.cpp:34,42)
+        a.scale[k] = c * s2 * tau;
+        a.hinv[k] = 1.0 / (2.0 * s2);
+        a.cst[k] = -(log_tau + log_si + log(s2)) / 2;
+    }
+}
+
+}  // namespace
+
+int identity_tail(const locus_hip_tail_args& a, int phase, hipStream_t st)
+{
+    if (phase == 0) {
+        hipLaunchKernelGGL(tail_resp_kernel, dim3(1), dim3(1024), 0, st, a);
+    } else {
+        double* part = a.part;
+        hipLaunchKernelGGL(tail_cov_kernel, dim3(kCovBlocks), dim3(256), 0, st, a, part);
+        hipLaunchKernelGGL(tail_final_kernel, dim3(1), dim3(1024), 0, st, a, part);
+    }
+    LOCUS_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace locus

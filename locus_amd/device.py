@@ -139,6 +139,11 @@ def gamma_rows(gam_plane, p, d, eps=None):
     return rs, ent
 
 
+def identity_tail(args, phase):
+    """locus_hip_identity_tail_dev on a filled _lib.TailArgs (locus_core.FusedTail)."""
+    _lib.check(_lib.lib().locus_hip_identity_tail_dev(ctypes.byref(args), int(phase), _stream()))
+
+
 def state_cols(state, p, d, s2k=None, s2jk=None, nchunks=64):
     nchunks = max(1, min(int(nchunks), p))
     part = torch.empty((nchunks, 3, d), dtype=F64, device=state.device)

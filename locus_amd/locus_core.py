@@ -400,6 +400,104 @@ class IdentityTail(IdentityHost):
         return s_bg, e_om
 
 
+class FusedTail(IdentityTail):
+    """IdentityTail with the steady-state tail in three HIP kernels (csrc/tail.hip,
+    `locus_hip_identity_tail_dev`) instead of ~150 tensor kernels: phase 0 behind the sweep, the
+    all-reduce, phase 1 -- ELBO of the iteration that ended AND the constants of the next one, into
+    one of two buffer sets that alternate, so that what the running sweep reads is never
+    overwritten.  The first iteration's set-up (set_initial / the first prepare_iteration) and any
+    prepare_iteration the engine did not announce use the tensor path of the base class."""
+
+    wants_ent_vector = True
+
+    def __init__(self, *args, dv=None, **kw):
+        super().__init__(*args, **kw)
+        self._dvl = dv
+        self._sets = None
+
+    def _alloc(self):
+        import torch
+        dev, f64 = self._dev, torch.float64
+        d_loc = self.tau_t.numel()
+        mk = lambda *shape: torch.zeros(shape, dtype=f64, device=dev)  # noqa: E731
+        self._sets = [dict(vec=mk(5, d_loc), lp=mk(2, self.p), scal=mk(8)) for _ in range(2)]
+        self._buf = mk(self.p + 2)
+        self._part = mk(192)
+        self._turn = 0
+        self._next = None
+
+    def end_iteration(self, stats, rs_gam_local, ent_local, c=1.0, with_elbo=True, sync=True,
+                      c_next=None):
+        import torch
+        from . import _lib
+        if self._sets is None:
+            self._alloc()
+        dvl = self._dvl
+        self.stats_t = stats
+        self._last = (rs_gam_local, ent_local)
+        st = self._sets[self._turn]
+        self._turn ^= 1
+        world1 = self.comm.world == 1
+        a = _lib.TailArgs()
+        a.n, a.p, a.d_loc, a.d_total = self.n, self.p, self.tau_t.numel(), self.d
+        a.a, a.b = self.a_t.data_ptr(), self.b_t.data_ptr()
+        a.eta, a.kappa = self.eta_t.data_ptr(), self.kappa_t.data_ptr()
+        a.lam, a.nu = self.lam, self.nu
+        a.stats = stats.data_ptr()
+        tau, s2, si = self.tau_t.contiguous(), self.s2_t.contiguous(), self.si_t
+        a.tau, a.s2, a.si_in = tau.data_ptr(), s2.data_ptr(), si.data_ptr()
+        a.ent = ent_local.data_ptr() if (with_elbo and ent_local is not None) else None
+        a.shard2 = self._buf[self.p:].data_ptr()
+        a.scal = st["scal"].data_ptr()
+        a.with_elbo = 1 if with_elbo else 0
+        a.c_next = float(c_next if c_next is not None else 1.0)
+        a.part = self._part.data_ptr()
+        dvl.identity_tail(a, 0)
+        if world1:
+            self.rs_gam_t = rs_gam_local.reshape(-1)
+        else:
+            self._buf[: self.p].copy_(rs_gam_local.reshape(-1))
+            self.comm.all_reduce_sum_(self._buf)
+            self.rs_gam_t = self._buf[: self.p]
+        a.rs_gam = self.rs_gam_t.data_ptr()
+        if c_next is not None:
+            a.lo, a.l1 = st["lp"][0].data_ptr(), st["lp"][1].data_ptr()
+            v = st["vec"]
+            a.tau_next, a.s2_next, a.scale, a.hinv, a.cst = (v[i].data_ptr() for i in range(5))
+        dvl.identity_tail(a, 1)
+        self._keep = (tau, s2, si, stats, ent_local, rs_gam_local)  # alive until the kernels ran
+        scal = st["scal"]
+        self.sum_gam_t, self.sum_tau_m2_t = scal[1], scal[2]
+        self._c_last = c
+        self._next = None
+        if c_next is not None:
+            v = st["vec"]
+            self._next = dict(lo=st["lp"][0], l1=st["lp"][1], log_sig2_inv_vb=scal[5], tau_vb=v[0],
+                              sig2_beta_vb=v[1], sig2_inv_vb=scal[4], c=float(c_next), scale=v[2],
+                              hinv=v[3], cst=v[4], s2k=v[1])
+        if not with_elbo:
+            return None
+        return float(scal[0]) if sync else scal[0]
+
+    def prepare_iteration(self, c=1.0):
+        nxt, self._next = getattr(self, "_next", None), None
+        if nxt is not None and nxt["c"] == float(c):
+            return nxt
+        return super().prepare_iteration(c)
+
+    def held_out_elbo_(self, n_test, rss_test):
+        n_fit, st_fit = self.n, self.stats_t
+        # the fitted sig2_inv_vb may live in the buffer set this call is about to write
+        self.si_t = self.si_t.clone()
+        try:
+            self.n = int(n_test)
+            st = st_fit.clone()
+            st[3] = self._t(rss_test, self._dev)
+            return self.end_iteration(st, *self._last)
+        finally:
+            self.n, self.stats_t = n_fit, st_fit
+
+
 class IdentityEngine:
     """One GPU's shard of the identity-link model."""
 
@@ -477,7 +575,11 @@ class IdentityEngine:
                                                                       device=self.device)
         if resident:
             # everything after the sweep is queued on the device; the ELBO is the one read-back
-            lb = self.host.end_iteration(self.stats, rs_gam, tail, c, with_elbo, sync=False)
+            if getattr(self.host, "wants_ent_vector", False):
+                lb = self.host.end_iteration(self.stats, rs_gam, ent if with_elbo else None, c,
+                                             with_elbo, sync=False, c_next=c_next)
+            else:
+                lb = self.host.end_iteration(self.stats, rs_gam, tail, c, with_elbo, sync=False)
             if c_next is not None:
                 self._prm_next = self.host.prepare_iteration(c_next)
             if after_launch is not None:
@@ -567,8 +669,10 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
                                        (d,))[k_lo:k_hi]
     hyper_loc["kappa"] = np.broadcast_to(np.asarray(list_hyper["kappa"], dtype=np.float64),
                                          (d,))[k_lo:k_hi]
-    host = IdentityTail(n, p, d, hyper_loc, np.asarray(tau_vb)[k_lo:k_hi],
-                        np.asarray(sig2_beta_vb)[k_lo:k_hi], comm)
+    host_cls = FusedTail if hasattr(dv, "identity_tail") else IdentityTail  # CPU test backend: tensors
+    host = host_cls(n, p, d, hyper_loc, np.asarray(tau_vb)[k_lo:k_hi],
+                    np.asarray(sig2_beta_vb)[k_lo:k_hi], comm, **(
+                        dict(dv=dv) if host_cls is FusedTail else {}))
     px = dv.PackedX(dv.to_device_colmajor(X, device))
     Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
     state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)

@@ -8,8 +8,8 @@ sys.path.insert(0, ".")
 import bench
 from locus_amd import device as dv
 from locus_amd.comm import Comm
-from locus_amd.locus_core import IdentityEngine, IdentityHost, IdentityTail
-HostCls = IdentityHost if os.environ.get('STEP_HOST') == 'host' else IdentityTail
+from locus_amd.locus_core import FusedTail, IdentityEngine, IdentityHost, IdentityTail
+HostCls = {'host': IdentityHost, 'tail': IdentityTail}.get(os.environ.get('STEP_HOST'), FusedTail)
 SYNC = os.environ.get('STEP_SYNC', '1') != '0'
 
 n, p, d = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (1000, 50000, 10000)
@@ -23,7 +23,8 @@ hyper["lambda"] = 1e-2
 tau0 = np.full(d, 1 / med)
 state = torch.empty((3, p, d), dtype=torch.float64, device=dev)
 state[0].uniform_(0, 1e-3); state[1].normal_(0, 1)
-host = HostCls(n, p, d, hyper, tau0, 1.0 / np.random.default_rng(1).gamma(2.0, 1e-2 * tau0), Comm())
+host = HostCls(n, p, d, hyper, tau0, 1.0 / np.random.default_rng(1).gamma(2.0, 1e-2 * tau0), Comm(),
+               **(dict(dv=dv) if HostCls is FusedTail else {}))
 eng = IdentityEngine(px, Y, state, host, dev)
 eng.initialise()
 T = {}
@@ -48,7 +49,7 @@ for it in range(K + 1):
         nxt = [rng.permutation(p).astype(np.float64)]
     def draw():  # overlaps the sweep, as in locus_core_
         tp = time.perf_counter(); nxt.append(rng.permutation(p).astype(np.float64)); T["perm"] = T.get("perm", 0) + time.perf_counter() - tp
-    kw = dict(c_next=1.0) if HostCls is IdentityTail else {}
+    kw = dict(c_next=1.0) if HostCls is not IdentityHost else {}
     eng.iterate(nxt.pop(0), 1.0, with_elbo=True, after_launch=draw, **kw)
 torch.cuda.synchronize(); tot = (time.perf_counter() - t0) / K
 print(f"{HostCls.__name__} n={n} p={p} d={d}: total {tot*1e3:.3f} ms/iteration; " + " ".join(f"{k}={v/K*1e3:.2f}" for k, v in T.items()))

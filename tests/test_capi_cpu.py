@@ -35,6 +35,12 @@ def test_sweep_args_struct_matches_header():
     assert ctypes.sizeof(_lib.SweepArgs) == 8 * (3 + 5 + 4 + 1 + 3 + 1 + 3 + 1 + 2) + 16 + 8
 
 
+def test_tail_args_struct_matches_header():
+    from locus_amd import _lib
+    # 4 int64 + 4 ptr + 2 double + 5 ptr + 3 ptr + 2 int32 + double + 8 ptr
+    assert ctypes.sizeof(_lib.TailArgs) == 8 * (4 + 4 + 2 + 5 + 3) + 8 + 8 + 8 * 8
+
+
 @pytest.mark.parametrize("n,d", [(200, 20), (1000, 1000), (1000, 1250), (1000, 10000),
                                  (2000, 500), (1000, 2000), (64, 1), (2048, 8)])
 @pytest.mark.parametrize("logit", [0, 1])

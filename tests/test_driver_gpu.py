@@ -499,3 +499,117 @@ def test_locus_every_mode_on_gpu(hip, mode):
     assert list(vb["rmvd_x"]) == [p, p + 1]
     assert vb["gam_vb"].shape == (p, d) and np.all((vb["gam_vb"] >= 0) & (vb["gam_vb"] <= 1))
     assert np.all(np.isfinite(np.atleast_1d(vb["lb_opt"])))
+
+
+def test_fused_tail_matches_tensor_tail(hip):
+    """csrc/tail.hip (three kernels per iteration) against the same arithmetic as torch tensor
+    operations (IdentityTail), on made-up reduced statistics: annealed iterations without the
+    ELBO, then plain ones with it; ELBO, the scalars and every per-response / per-covariate
+    constant of the next sweep to 1e-12."""
+    import torch
+    from locus_amd import device as dv
+    from locus_amd.locus_core import FusedTail, IdentityTail
+    rng = np.random.default_rng(5)
+    n, p, d = 50, 300, 7
+    dev = torch.device("cuda:0")
+    hyper = dict(a=rng.uniform(0.5, 3.0, p), b=rng.uniform(5.0, 400.0, p),
+                 eta=rng.uniform(0.5, 2.0, d), kappa=rng.uniform(0.5, 2.0, d), nu=1.3)
+    hyper["lambda"] = 0.7
+    tau0, s20 = rng.uniform(0.5, 2.0, d), rng.uniform(1e-3, 1e-2, d)
+    A = IdentityTail(n, p, d, hyper, tau0, s20)
+    B = FusedTail(n, p, d, hyper, tau0, s20, dv=dv)
+
+    def stats_rs():
+        cs_gam = rng.uniform(0.0, 20.0, d)
+        cs_b2 = rng.uniform(0.0, 3.0, d)
+        st = np.stack([cs_gam, cs_b2 + rng.uniform(0.01, 1.0, d), cs_b2, rng.uniform(10.0, 80.0, d)])
+        return (torch.from_numpy(st).to(dev), torch.from_numpy(rng.uniform(0.0, d, p)).to(dev),
+                torch.from_numpy(rng.uniform(0.0, 0.05, p)).to(dev))
+
+    st, rs, _ = stats_rs()
+    A.set_initial(st.clone(), rs.clone())
+    B.set_initial(st.clone(), rs.clone())
+    ladder = [0.4, 0.7, 1.0, 1.0, 1.0]
+    A.begin_iteration(ladder[0])
+    B.begin_iteration(ladder[0])
+    for i, c in enumerate(ladder[:-1]):
+        c_next, with_elbo = ladder[i + 1], c == 1.0
+        st, rs, ent = stats_rs()
+        lbA = A.end_iteration(st.clone(), rs.clone(), ent.sum().reshape(1), c, with_elbo)
+        pa = A.begin_iteration(c_next)
+        lbB = B.end_iteration(st.clone(), rs.clone(), ent if with_elbo else None, c, with_elbo,
+                              c_next=c_next)
+        pb = B.begin_iteration(c_next)
+        if with_elbo:
+            assert abs(lbA - lbB) <= 1e-12 * abs(lbA), (i, lbA, lbB)
+        else:
+            assert lbA is None and lbB is None
+        for key in ("lo", "l1", "tau_vb", "sig2_beta_vb", "scale", "hinv", "cst", "s2k",
+                    "sig2_inv_vb", "log_sig2_inv_vb"):
+            np.testing.assert_allclose(pb[key].cpu().numpy(), pa[key].cpu().numpy(), rtol=1e-12,
+                                       atol=1e-14, err_msg=f"iteration {i}: {key}")
+        assert abs(A.sum_gam - B.sum_gam) <= 1e-12 * abs(A.sum_gam)
+        assert abs(A.sig2_inv_vb - B.sig2_inv_vb) <= 1e-12 * abs(A.sig2_inv_vb)
+    rss_test = rng.uniform(5.0, 40.0, d)
+    si = B.sig2_inv_vb
+    lbA, lbB = A.held_out_elbo_(31, rss_test), B.held_out_elbo_(31, rss_test)
+    assert abs(lbA - lbB) <= 1e-12 * abs(lbA)
+    assert B.sig2_inv_vb == si  # the fitted value survives the held-out evaluation
+
+
+def _shard_worker(rank, world, port, q):
+    """One of two ranks that share the GPU (gloo: RCCL refuses two ranks on one device)."""
+    try:
+        import os
+        import sys
+        import torch
+        import torch.distributed as dist
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path[:0] = [here, os.path.dirname(here)]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import ref_driver
+        from locus_amd.comm import DistComm
+        from locus_amd.locus_core import locus_core_
+        sim, hyper, init, perm_fn = _setup(n=150, p=120, d=37, p0=9, seed=11)
+        kw = dict(tol=1e-30, maxit=4, perm_fn=perm_fn, full_output=True)
+        got = locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                          init["sig2_beta_vb"], init["tau_vb"], comm=DistComm(),
+                          device=torch.device("cuda:0"), **kw)
+        if rank == 0:
+            ref = ref_driver.locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"],
+                                         init["mu_beta_vb"], init["sig2_beta_vb"], init["tau_vb"], **kw)
+            for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1", "tau_vb", "sig2_beta_vb"):
+                np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+            assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+            assert abs(got["sig2_inv_vb"] - ref["sig2_inv_vb"]) <= 1e-10 * abs(ref["sig2_inv_vb"])
+        t = torch.from_numpy(np.concatenate([got["gam_vb"].ravel(), [got["lb_opt"]]]))
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "ranks disagree"
+        dist.destroy_process_group()
+        q.put((rank, None))
+    except BaseException as e:  # noqa: BLE001 -- report to the parent, which fails the test
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e)))
+
+
+def test_identity_two_ranks_share_the_gpu(oracle, hip):
+    """The d-sharded driver with the fused iteration tail on real device buffers: two ranks (gloo)
+    on one GPU, 19 + 18 responses, against the single-process oracle driver."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=60)
+    for rank, err in res:
+        assert err is None, f"rank {rank}: {err}"
