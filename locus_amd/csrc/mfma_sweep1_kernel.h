@@ -219,26 +219,22 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             const bool bx_ok = bx >= 0 && bx < P.nblk;
             const bool xw = (CS == 1) && (m == 0) && bx_ok;  // clusters: the chain wave does it
             double2 axr[(CS > 1) ? 1 : L - 1][2];
+            // clusters: this wave's lag (m + 1, for m = 1 .. L-2) of the cross-block corrections
+            const bool do_corr = (CS > 1) && bx_ok && m >= 1 && m <= L - 2;
+            double cdl[4] = {0.0, 0.0, 0.0, 0.0};
+            d4 ccx = d4{0.0, 0.0, 0.0, 0.0};
             if constexpr (CS > 1) {
-                if (bx_ok && m >= 1 && m <= L - 2) {
-                    // this wave's lag: m + 1 (index l - 1 = m)
-                    const int lagi = m;
+                // (requests only; the MFMAs and the result go into the operand stream below, a
+                // quarter and a half of the way through, so that neither the LDS latency nor the
+                // latency of four dependent MFMAs is paid at the top of the iteration)
+                if (do_corr) {
                     const double2* ap =
-                        reinterpret_cast<const double2*>(axl + ((bx & 1) * (L - 1) + lagi) * 256) + 2 * lane;
+                        reinterpret_cast<const double2*>(axl + ((bx & 1) * (L - 1) + m) * 256) + 2 * lane;
                     axr[0][0] = ap[0];
                     axr[0][1] = ap[1];
-                    {
-                        const double* dp = dl + ((bx - (m + 1)) & (DR - 1)) * 256 + q * 16 + r;
-                        const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
-                        d4 cc = d4{0.0, 0.0, 0.0, 0.0};
+                    const double* dp = dl + ((bx - (m + 1)) & (DR - 1)) * 256 + q * 16 + r;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            cc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], dp[64 * c], cc, 0, 0, 0);
-                        double* co = cx + (m - 1) * 256 + lane;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) co[64 * g] = cc[g];
-                        lds_publish(&cxf[m - 1], it);
-                    }
+                    for (int c = 0; c < 4; ++c) cdl[c] = dp[64 * c];
                 }
             } else if (xw) {  // used at the end of this iteration only
 #pragma unroll
@@ -252,6 +248,22 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
             auto slot = [&](auto oc) {
                 constexpr int o = decltype(oc)::value;
+                if constexpr (CS > 1 && o == NOP / 4) {
+                    if (do_corr) {
+                        const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            ccx = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], cdl[c], ccx, 0, 0, 0);
+                    }
+                }
+                if constexpr (CS > 1 && o == NOP / 2) {
+                    if (do_corr) {
+                        double* co = cx + (m - 1) * 256 + lane;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) co[64 * g] = ccx[g];
+                        lds_publish(&cxf[m - 1], it);
+                    }
+                }
                 constexpr int sl = (o >> 1) % NR2;
                 const double a = (o & 1) ? ring[sl].y : ring[sl].x;
                 if constexpr ((o & 1) != 0) {
