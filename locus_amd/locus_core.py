@@ -594,6 +594,77 @@ class IdentityEngine:
         stats = h[:-1].reshape(4, self.d_loc)
         return self.host.end_iteration(stats, rs_gam, float(h[-1]), c, with_elbo)
 
+    def iterate_scheme(self, scheme, c=1.0, with_elbo=True, c_next=None, k_order=None,
+                       j_orders=None):
+        """One iteration of the reference's internal schemes (R/locus_core.R:97-161; "used only
+        internally, convergence not ensured"):
+          "x-y"  coreBatch: every (j, k) at once from the residual of the last iteration -- two
+                 GEMMs on the matrix cores around the element-wise update (src/coreBatch.cpp:19-43);
+          "x"    the same update response by response (:97-117); the responses do not interact
+                 inside an iteration, so the result is that of "x-y" whatever the order;
+          "0"    response by response with log_om_vb refreshed from rowSums(gam_vb) in between
+                 (:135-161): d sweeps of one response each, in the order k_order, response k over
+                 the covariates in the order j_orders(k).  Sequential over the responses: one GPU."""
+        dv, t, host = self.dv, self.torch, self.host
+        n, p, d = self.n, self.p, self.d_loc
+        resident = getattr(host, "device_resident", False)
+        nxt = getattr(self, "_prm_next", None)
+        self._prm_next = None
+        if resident and nxt is not None and nxt["c"] == float(c):
+            prm = host.commit_iteration(nxt)
+        else:
+            prm = host.begin_iteration(c)
+        up = self._up
+        if scheme in ("x", "x-y"):
+            if float(c) != 1.0:
+                raise NotImplementedError("annealing with the batched schemes: the element-wise "
+                                          "kernel of coreBatch has no annealing factor")
+            log_si = float(prm["log_sig2_inv_vb"])
+            # T = X'(Y - mat_x_m1) into the mu plane, then mu, gam, beta element-wise
+            dv.gemm(p, d, n, self.px.Xp, self.px.ld, 1, self.R, 1, n, self.state[1], d, 1)
+            cstk = -up(prm["cst"]) - log_si / 2              # log_tau / 2 + log(sig2_beta) / 2
+            dv.batch_update(self.state, up(prm["lo"]), up(prm["l1"]), up(prm["scale"]),
+                            up(prm["hinv"]), cstk, log_si, n - 1, 0, p, d)
+            M = t.empty((d, n), dtype=t.float64, device=self.device).t()
+            dv.gemm(n, d, p, self.px.Xp, 1, self.px.ld, self.state[2], d, 1, M, 1, n)
+            self.R = dv.residual(self.Y, M)
+            self.stats[:3] = dv.state_cols(self.state, p, d, s2k=up(prm["s2k"]))
+            self.stats[3] = (self.R * self.R).sum(dim=0)
+        elif scheme == "0":
+            if host.comm.world != 1:
+                raise NotImplementedError('scheme "0" is sequential over the responses: one rank')
+            if getattr(self, "_sw1", None) is None:
+                self._sw1 = dv.Sweeper(self.px, 1, self.device)
+                self._stats1 = t.empty((4, 1), dtype=t.float64, device=self.device)
+            scale, hinv, cst, s2k = (up(prm[key]) for key in ("scale", "hinv", "cst", "s2k"))
+            for k in k_order:
+                k = int(k)
+                lo, l1 = host._log_om_terms(c)              # from the CURRENT rowSums(gam_vb), :139
+                st1 = self.state[:, :, k].contiguous()      # [3][p] = [3][p][1]
+                g_old = st1[0].clone()
+                self._sw1.identity(up(j_orders(k)), lo, l1, scale[k:k + 1], hinv[k:k + 1],
+                                   cst[k:k + 1], s2k[k:k + 1], c, self.R[:, k], st1, self._stats1)
+                self._sw1.status()
+                self.state[:, :, k] = st1
+                self.stats[:, k] = self._stats1[:, 0]
+                host.rs_gam_t = host.rs_gam_t + (st1[0] - g_old)      # :157
+        else:
+            raise ValueError("Batch scheme not defined. Exit.")
+        rs_gam, ent = dv.gamma_rows(self.state[0], p, d, eps=host.ent_eps if with_elbo else None)
+        if resident and getattr(host, "wants_ent_vector", False):
+            lb = host.end_iteration(self.stats, rs_gam, ent if with_elbo else None, c, with_elbo,
+                                    c_next=c_next)
+        elif resident:
+            tail = ent.sum().reshape(1) if with_elbo else t.zeros(1, dtype=t.float64,
+                                                                  device=self.device)
+            lb = host.end_iteration(self.stats, rs_gam, tail, c, with_elbo)
+        else:
+            lb = host.end_iteration(self.stats.cpu().numpy(), rs_gam,
+                                    float(ent.sum()) if with_elbo else 0.0, c, with_elbo)
+        if resident and c_next is not None:
+            self._prm_next = host.prepare_iteration(c_next)
+        return lb
+
     def download(self):
         """gam_vb, mu_beta_vb, beta_vb (p x d_loc) and mat_x_m1 (n x d_loc) as numpy, R layout;
         each is fetched when first asked for."""
@@ -635,7 +706,7 @@ def checkpoint_clean_up_(checkpoint_path):  # R/utils.R:339-352
 def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol, maxit,
                 anneal=None, verbose=False, batch="y", full_output=False, debug=True,
                 checkpoint_path=None, perm_fn=None, comm=None, device=None, trace=None,
-                held_out=None, _test_backend=None):
+                held_out=None, k_perm_fn=None, perm0_fn=None, _test_backend=None):
     """R/locus_core.R:8-255 on the GPU.  Y (n x d) must be centred and X (n x p) standardised.
 
     `held_out = (Y_test, X_test)` adds `lb_held_out`, the ELBO of the fit on those rows (the
@@ -651,9 +722,10 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
     """
     dv, device = resolve_backend(_test_backend, device)
     import torch
-    if batch != "y":
-        raise NotImplementedError("only the 'y' scheme (coreLoop) is device-resident; "
-                                  "coreBatch is available as locus_amd.coreBatch")
+    if batch not in ("y", "x", "x-y", "0"):
+        raise ValueError("Batch scheme not defined. Exit.")                 # :159-161
+    if batch == "x-y" and anneal is not None:
+        raise ValueError("Annealing not implemented for this scheme. Exit.")  # :123-124
     comm = comm or Comm()
     Y = np.asarray(Y, dtype=np.float64)
     X = np.asarray(X, dtype=np.float64)
@@ -663,6 +735,15 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
     if perm_fn is None:
         rng = np.random.default_rng(0)
         perm_fn = lambda it: rng.permutation(p).astype(np.float64)  # noqa: E731
+    if batch in ("x", "0"):
+        # the internal schemes of R/locus_core.R:97-161: sample(1:d) per iteration (:102,137) and,
+        # for "0", sample(1:p) per response (:142)
+        if k_perm_fn is None:
+            rng_k = np.random.default_rng(1)
+            k_perm_fn = lambda it: rng_k.permutation(d)  # noqa: E731
+        if perm0_fn is None:
+            rng_0 = np.random.default_rng(2)
+            perm0_fn = lambda it, k: rng_0.permutation(p).astype(np.float64)  # noqa: E731
 
     hyper_loc = dict(list_hyper)
     hyper_loc["eta"] = np.broadcast_to(np.asarray(list_hyper["eta"], dtype=np.float64),
@@ -700,8 +781,14 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
             if it < maxit:
                 nxt[it + 1] = np.ascontiguousarray(perm_fn(it + 1), dtype=np.float64)
         c_next = (float(ladder[it]) if it < len(ladder) else 1.0) if annealing else 1.0
-        lb = eng.iterate(ind, c, with_elbo=not annealing, after_launch=draw_next,
-                         c_next=c_next if it < maxit else None)
+        if batch == "y":
+            lb = eng.iterate(ind, c, with_elbo=not annealing, after_launch=draw_next,
+                             c_next=c_next if it < maxit else None)
+        else:
+            lb = eng.iterate_scheme(
+                batch, c, with_elbo=not annealing, c_next=c_next if it < maxit else None,
+                k_order=k_perm_fn(it) if batch in ("x", "0") else None,
+                j_orders=(lambda k, it=it: np.ascontiguousarray(perm0_fn(it, k), dtype=np.float64)))
         if annealing:                                                    # :177-190
             c = c_next
             if np.isclose(c, 1.0, rtol=1.5e-8, atol=0):

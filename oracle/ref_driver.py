@@ -391,8 +391,10 @@ def elbo_(Y, a, a_vb, b, b_vb, beta_vb, eta, gam_vb, kappa, lam, nu, sig2_beta_v
 
 def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol, maxit,
                 perm_fn, anneal=None, batch="y", debug=True, full_output=True,
-                trace=None):
-    """R/locus_core.R:8-255.  `trace`, if a list, receives (it, lb_new) per iteration."""
+                trace=None, k_perm_fn=None, perm0_fn=None):
+    """R/locus_core.R:8-255.  `trace`, if a list, receives (it, lb_new) per iteration.
+    The internal schemes "x" and "0" sweep the responses in the order k_perm_fn(it) (sample(1:d),
+    :102,137); "0" sweeps the covariates of response k in the order perm0_fn(it, k) (:142)."""
     Y = np.asfortranarray(Y, dtype=np.float64)
     X = np.asfortranarray(X, dtype=np.float64)
     n, d = Y.shape
@@ -444,9 +446,38 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
                               log_tau_vb, beta_vb, mat_x_m1, mu_beta_vb, sig2_beta_vb,
                               tau_vb, shuffled_ind, c)
         elif batch == "x-y":                                            # :121-133
+            if annealing:
+                raise RuntimeError("Annealing not implemented for this scheme. Exit.")
             c_oracle.coreBatch(X, Y, gam_vb, log_om_vb, log_1_min_om_vb, log_sig2_inv_vb,
                                log_tau_vb, beta_vb, mat_x_m1, mu_beta_vb, sig2_beta_vb,
                                tau_vb)
+        elif batch == "x":                                              # :97-117
+            for k in k_perm_fn(it):
+                k = int(k)
+                mu_beta_vb[:, k] = c * sig2_beta_vb[k] * tau_vb[k] * (
+                    (Y[:, k] - mat_x_m1[:, k]) @ X + (n - 1) * beta_vb[:, k])
+                gam_vb[:, k] = np.exp(-log_one_plus_exp_(c * (
+                    log_1_min_om_vb - log_om_vb - log_tau_vb[k] / 2 - log_sig2_inv_vb / 2
+                    - mu_beta_vb[:, k] ** 2 / (2 * sig2_beta_vb[k]) - np.log(sig2_beta_vb[k]) / 2)))
+                beta_vb[:, k] = mu_beta_vb[:, k] * gam_vb[:, k]
+                mat_x_m1[:, k] = X @ beta_vb[:, k]
+        elif batch == "0":                                              # :135-161
+            for k in k_perm_fn(it):
+                k = int(k)
+                log_om_vb = update_log_om_vb(a, digam_sum, rs_gam, c)
+                log_1_min_om_vb = update_log_1_min_om_vb(b, d, digam_sum, rs_gam, c)
+                for j in perm0_fn(it, k):
+                    j = int(j)
+                    mat_x_m1[:, k] -= X[:, j] * beta_vb[j, k]
+                    mu_beta_vb[j, k] = c * sig2_beta_vb[k] * tau_vb[k] * (
+                        (Y[:, k] - mat_x_m1[:, k]) @ X[:, j])
+                    gam_vb[j, k] = np.exp(-log_one_plus_exp_(c * (
+                        log_1_min_om_vb[j] - log_om_vb[j] - log_tau_vb[k] / 2 - log_sig2_inv_vb / 2
+                        - mu_beta_vb[j, k] ** 2 / (2 * sig2_beta_vb[k])
+                        - np.log(sig2_beta_vb[k]) / 2)))
+                    beta_vb[j, k] = mu_beta_vb[j, k] * gam_vb[j, k]
+                    mat_x_m1[:, k] += X[:, j] * beta_vb[j, k]
+                rs_gam = gam_vb.sum(axis=1)
         else:
             raise ValueError("Batch scheme not defined. Exit.")
         rs_gam = gam_vb.sum(axis=1)

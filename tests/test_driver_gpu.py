@@ -613,3 +613,34 @@ def test_identity_two_ranks_share_the_gpu(oracle, hip):
         pr.join(timeout=60)
     for rank, err in res:
         assert err is None, f"rank {rank}: {err}"
+
+
+@pytest.mark.parametrize("batch", ["x-y", "x", "0"])
+def test_identity_internal_batch_schemes(oracle, hip, batch):
+    """The reference's internal schemes of locus_core_ (R/locus_core.R:97-161; "convergence not
+    ensured"): coreBatch for every (j, k) at once, the same response by response, and the plain
+    double loop with log_om_vb refreshed after every response."""
+    from oracle import ref_driver
+    from locus_amd.locus_core import locus_core_
+    sim, hyper, init, perm_fn = _setup(n=90, p=40, d=6, p0=5, seed=3)
+    p, d = 40, 6
+    kt, jt = {}, {}
+
+    def k_perm_fn(it):
+        if it not in kt:
+            kt[it] = np.random.default_rng(100 + it).permutation(d)
+        return kt[it]
+
+    def perm0_fn(it, k):
+        if (it, k) not in jt:
+            jt[(it, k)] = np.random.default_rng(1000 * it + k).permutation(p).astype(np.float64)
+        return jt[(it, k)]
+    kw = dict(tol=1e-30, maxit=3, perm_fn=perm_fn, full_output=True, batch=batch, debug=False,
+              k_perm_fn=k_perm_fn, perm0_fn=perm0_fn)
+    ref = ref_driver.locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                                 init["sig2_beta_vb"], init["tau_vb"], **kw)
+    got = locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                      init["sig2_beta_vb"], init["tau_vb"], **kw)
+    for key in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1"):
+        np.testing.assert_allclose(got[key], ref[key], rtol=1e-9, atol=1e-12, err_msg=key)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
