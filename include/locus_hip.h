@@ -303,6 +303,10 @@ int locus_hip_probit_w_dev(const double* Y, const double* M, const double* Zmu, 
  *           log_sig2_inv_vb of the next iteration at annealing factor c_next; lo / l1 =
  *           log_om_vb / log_1_min_om_vb, and tau_next, s2_next, scale, hinv, cst = tau_vb,
  *           sig2_beta_vb and the per-response constants locus_hip_sweep_dev takes (NULL: skipped).
+ *   phase 2 = phase 1 for models whose covariate-wise terms are not those of the Beta prior on
+ *           omega (structured prior, R/locus_struct_core.R:201-221): the caller fills part[0..2] =
+ *           {sum(gam_vb), covariate terms of e_beta_gamma_, the other replicated ELBO terms} and
+ *           zeroes part[3..191]; a, b, rs_gam, lo, l1 are not used.
  * *si_in is sig2_inv_vb of the iteration that ended (read by both phases; it may be scal[4] of
  * the previous call's scal buffer). */
 typedef struct locus_hip_tail_args {

@@ -642,7 +642,7 @@ int locus_hip_transpose_dev(const double* in, double* out, int64_t rows, int64_t
 
 int locus_hip_identity_tail_dev(const locus_hip_tail_args* a, int phase, void* stream)
 {
-    LOCUS_REQUIRE(a != nullptr && (phase == 0 || phase == 1), "identity_tail: bad arguments");
+    LOCUS_REQUIRE(a != nullptr && phase >= 0 && phase <= 2, "identity_tail: bad arguments");
     LOCUS_REQUIRE(a->n >= 1 && a->p >= 1 && a->d_loc >= 1 && a->d_total >= a->d_loc &&
                       a->p < (1ll << 31) && a->d_loc < (1ll << 31),
                   "identity_tail: bad dimensions");
@@ -650,6 +650,11 @@ int locus_hip_identity_tail_dev(const locus_hip_tail_args* a, int phase, void* s
                   "identity_tail: NULL device pointer");
     if (phase == 0)
         LOCUS_REQUIRE(a->tau && a->s2, "identity_tail: phase 0 needs tau, s2");
+    else if (phase == 2)
+        LOCUS_REQUIRE(a->part && a->lo == nullptr && a->l1 == nullptr &&
+                          (a->tau_next == nullptr ||
+                           (a->s2_next && a->scale && a->hinv && a->cst)),
+                      "identity_tail: phase 2 needs part, no lo / l1, and complete output sets");
     else
         LOCUS_REQUIRE(a->a && a->b && a->rs_gam && a->part && (a->lo == nullptr) == (a->l1 == nullptr) &&
                           (a->tau_next == nullptr ||

@@ -219,7 +219,10 @@ int identity_tail(const locus_hip_tail_args& a, int phase, hipStream_t st)
         hipLaunchKernelGGL(tail_resp_kernel, dim3(1), dim3(1024), 0, st, a);
     } else {
         double* part = a.part;
-        hipLaunchKernelGGL(tail_cov_kernel, dim3(kCovBlocks), dim3(256), 0, st, a, part);
+        // phase 2: the caller filled part[0..2] = {sum(gam_vb), covariate terms of e_beta_gamma_,
+        // remaining replicated ELBO terms} itself (structured prior) and zeroed the rest
+        if (phase == 1)
+            hipLaunchKernelGGL(tail_cov_kernel, dim3(kCovBlocks), dim3(256), 0, st, a, part);
         hipLaunchKernelGGL(tail_final_kernel, dim3(1), dim3(1024), 0, st, a, part);
     }
     LOCUS_HIP_CHECK(hipGetLastError());

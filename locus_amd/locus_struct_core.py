@@ -158,6 +158,144 @@ class StructHost(HostBase):
                      + E.e_sig2_inv_(self.lam, lambda_vb, log_sig2_inv_vb, self.nu, nu_vb, si))
 
 
+class StructTail(StructHost):
+    """StructHost whose per-response arithmetic, scalars and ELBO run in csrc/tail.hip
+    (`locus_hip_identity_tail_dev`, phases 0 and 2) behind the sweep: the response-wise sums of
+    the ELBO and the constants of the next sweep never visit the host, theta_vb and its terms stay
+    tensor operations (R/update_vb.R:315-319, R/elbo.R:98-104,166-180), and an iteration ends with
+    ONE read-back, of the ELBO.  The first iteration's set-up uses the numpy path of the base class."""
+
+    device_resident = True
+    wants_ent_vector = True
+
+    def __init__(self, *args, dv=None, **kw):
+        super().__init__(*args, **kw)
+        self._dvl, self._sets, self._next = dv, None, None
+        self.tau_t = self.s2_t = self.si_t = None
+
+    def _host(name, tname):   # host views of the device-resident quantities (outputs)
+        def get(self):
+            tt = getattr(self, tname, None)
+            if tt is None:
+                return self.__dict__.get("_" + name)
+            return float(tt) if tt.dim() == 0 else tt.cpu().numpy()
+
+        def put(self, v):
+            self.__dict__["_" + name] = v
+        return property(get, put)
+
+    tau_vb = _host("tau_vb", "tau_t")
+    sig2_beta_vb = _host("sig2_beta_vb", "s2_t")
+    sig2_inv_vb = _host("sig2_inv_vb", "si_t")
+    del _host
+
+    def set_initial(self, stats, rs_gam_local):
+        import torch
+        st = stats.cpu().numpy() if torch.is_tensor(stats) else stats
+        super().set_initial(st, rs_gam_local)
+
+    def begin_iteration(self, c=1.0):
+        """First iteration (and any iteration the engine did not announce): the numpy path of the
+        base class, its results moved to the device."""
+        import torch
+        if self._next is not None and self._next["c"] == float(c):
+            return self.commit_iteration(self.prepare_iteration(c))
+        self.tau_t = self.s2_t = self.si_t = None         # the properties fall back to numpy
+        prm = super().begin_iteration(c)
+        dev = self.theta_t.device
+        up = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True)).to(dev)  # noqa: E731
+        out = dict(lo=prm["lo"], l1=prm["l1"], c=1.0, scale=up(prm["scale"]), hinv=up(prm["hinv"]),
+                   cst=up(prm["cst"]), s2k=up(prm["s2k"]), tau_vb=up(self.tau_vb),
+                   sig2_beta_vb=up(self.sig2_beta_vb),
+                   sig2_inv_vb=torch.tensor(float(self.sig2_inv_vb), dtype=torch.float64, device=dev))
+        return self.commit_iteration(out)
+
+    def commit_iteration(self, prm):
+        self.tau_t, self.s2_t, self.si_t = prm["tau_vb"], prm["sig2_beta_vb"], prm["sig2_inv_vb"]
+        return prm
+
+    def prepare_iteration(self, c=1.0):
+        nxt, self._next = self._next, None
+        assert nxt is not None and nxt["c"] == float(c), "prepare_iteration without end_iteration"
+        return nxt
+
+    def end_iteration(self, stats, rs_gam_local, ent_local, c=1.0, with_elbo=True, sync=True,
+                      c_next=None):
+        import torch
+        from . import _lib
+        dev, f64 = rs_gam_local.device, torch.float64
+        self._on_device(dev)
+        d_loc, d = stats.shape[1], self.d
+        if self._sets is None:
+            mk = lambda *shape: torch.zeros(shape, dtype=f64, device=dev)  # noqa: E731
+            self._sets = [dict(vec=mk(5, d_loc), scal=mk(8)) for _ in range(2)]
+            self._buf, self._part, self._turn = mk(self.p + 2), mk(192), 0
+            up = lambda a: torch.from_numpy(np.array(np.broadcast_to(a, (d_loc,)), dtype=np.float64,  # noqa: E731
+                                                     copy=True)).to(dev)
+            self.eta_t, self.kappa_t = up(self.eta), up(self.kappa)
+        st = self._sets[self._turn]
+        self._turn ^= 1
+        a = _lib.TailArgs()
+        a.n, a.p, a.d_loc, a.d_total = self.n, self.p, d_loc, d
+        a.eta, a.kappa, a.lam, a.nu = self.eta_t.data_ptr(), self.kappa_t.data_ptr(), self.lam, self.nu
+        a.stats = stats.data_ptr()
+        tau, s2, si = self.tau_t.contiguous(), self.s2_t.contiguous(), self.si_t
+        a.tau, a.s2, a.si_in = tau.data_ptr(), s2.data_ptr(), si.data_ptr()
+        a.ent = ent_local.data_ptr() if ent_local is not None else None
+        a.shard2, a.scal = self._buf[self.p:].data_ptr(), st["scal"].data_ptr()
+        a.with_elbo, a.c_next, a.part = 1, 1.0, self._part.data_ptr()
+        self._dvl.identity_tail(a, 0)                     # shard-local sums of elbo_struct_ (:201-221)
+        if self.comm.world == 1:
+            self.rs_gam_t = rs_gam_local.reshape(-1)
+        else:
+            self._buf[: self.p].copy_(rs_gam_local.reshape(-1))
+            self.comm.all_reduce_sum_(self._buf)
+            self.rs_gam_t = self._buf[: self.p]
+        rs, th = self.rs_gam_t, self.theta_t
+        # W and theta (:127-129), as in StructHost.end_iteration
+        lp, l1p = self._log_phi()
+        dens = -th * th / 2 - LOG_SQRT_2PI
+        imr0 = -torch.exp(dens - l1p)
+        imr0 = torch.where(imr0 > -th, -th, imr0)
+        imr1 = torch.exp(dens - lp)
+        imr1 = torch.where(imr1 < -th, -th, imr1)
+        x = (imr1 - imr0) * rs + d * (th + imr0) + self.S_m0_t
+        theta = torch.empty_like(th)
+        for pos, _, V in self.groups_t:
+            theta[pos] = torch.bmm(V, x[pos].unsqueeze(-1)).squeeze(-1)
+        self.theta_t, self._lp = theta, None
+        lp, l1p = self._log_phi()                         # of the NEW theta_vb
+        dlt = theta - self.m0_t
+        quad = torch.zeros((), dtype=f64, device=dev)
+        for pos, S, _ in self.groups_t:
+            db = dlt[pos]
+            quad = quad + (db * torch.bmm(S, db.unsqueeze(-1)).squeeze(-1)).sum()
+        # {sum(gam_vb), covariate terms of e_beta_gamma_ (with log Phi for log omega), e_theta_}
+        self._part[:3] = torch.stack([
+            rs.sum(), (rs * lp).sum() + ((d - rs) * l1p).sum(),
+            self.blocks.e_theta_const - quad / 2 - d * self.blocks.sum_diag_sig2_theta / 2])
+        if c_next is not None:
+            v = st["vec"]
+            a.tau_next, a.s2_next, a.scale, a.hinv, a.cst = (v[i].data_ptr() for i in range(5))
+        self._dvl.identity_tail(a, 2)                     # scalars, ELBO, next sweep's constants
+        self._keep = (tau, s2, si, stats, ent_local, rs_gam_local)
+        scal = st["scal"]
+        self._next = None
+        if c_next is not None:
+            v = st["vec"]
+            self._next = dict(lo=lp, l1=l1p, c=1.0, scale=v[2], hinv=v[3], cst=v[4], s2k=v[1],
+                              tau_vb=v[0], sig2_beta_vb=v[1], sig2_inv_vb=scal[4])
+        self._sum_t = (scal[1], scal[2])
+        return float(scal[0]) if sync else scal[0]
+
+    sum_gam = property(lambda self: float(self._sum_t[0]) if getattr(self, "_sum_t", None)
+                       else self.__dict__.get("_sum_gam"),
+                       lambda self, v: self.__dict__.__setitem__("_sum_gam", v))
+    sum_tau_m2 = property(lambda self: float(self._sum_t[1]) if getattr(self, "_sum_t", None)
+                          else self.__dict__.get("_sum_tau_m2"),
+                          lambda self, v: self.__dict__.__setitem__("_sum_tau_m2", v))
+
+
 def locus_struct_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, list_struct,
                        tol, maxit, verbose=False, batch="y", full_output=False, debug=False,
                        perm_fn=None, comm=None, device=None, trace=None, _test_backend=None):
@@ -184,8 +322,10 @@ def locus_struct_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_v
     for key in ("eta", "kappa"):
         hyper_loc[key] = np.broadcast_to(np.asarray(list_hyper[key], dtype=np.float64),
                                          (d,))[k_lo:k_hi]
-    host = StructHost(n, p, d, hyper_loc, np.asarray(tau_vb)[k_lo:k_hi],
-                      np.asarray(sig2_beta_vb)[k_lo:k_hi], blocks, comm)
+    fused = hasattr(dv, "identity_tail")          # the CPU test backend keeps the numpy host side
+    host = (StructTail if fused else StructHost)(
+        n, p, d, hyper_loc, np.asarray(tau_vb)[k_lo:k_hi], np.asarray(sig2_beta_vb)[k_lo:k_hi],
+        blocks, comm, **(dict(dv=dv) if fused else {}))
     px = dv.PackedX(dv.to_device_colmajor(X, device))
     Y_dev = dv.to_device_colmajor(Y[:, k_lo:k_hi], device)
     state = torch.empty((3, p, k_hi - k_lo), dtype=torch.float64, device=device)
@@ -206,7 +346,8 @@ def locus_struct_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_v
         def draw_next(it=it):                                            # overlaps the sweep
             if it < maxit:
                 nxt[it + 1] = np.ascontiguousarray(perm_fn(it + 1), dtype=np.float64)
-        lb_new = eng.iterate(ind, 1.0, after_launch=draw_next)
+        lb_new = eng.iterate(ind, 1.0, after_launch=draw_next,
+                             **(dict(c_next=1.0 if it < maxit else None) if fused else {}))
         if trace is not None:
             trace.append((it, lb_new))
         if verbose and (it == 1 or it % 5 == 0):
