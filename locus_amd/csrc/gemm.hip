@@ -18,6 +18,8 @@
 // one workgroup per CU: 29 TFLOP/s, kept behind LOCUS_HIP_GEMM_TW=4 for experiments;
 // LOCUS_HIP_GEMM_KS / LOCUS_HIP_GEMM_BK override the other two choices).
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "kernels.h"
@@ -28,16 +30,22 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int LDP = 17;
 
-template <int TW, int KS, int BK>
+// SQ: some operand is squared on its way to LDS (g.sqA / g.sqB say which); OFF32: the elements of
+// a tile lie within 2^31 bytes after the tile's first element (non-negative strides), so an
+// element's address is a wave-uniform 64-bit base plus a 32-bit lane offset: the base advances
+// on the scalar unit and the K loop has no vector address arithmetic at all.  On gfx950 the fp64
+// MFMA runs on the SIMD's fp64 vector lanes (same 78.6 TFLOP/s peak): every vector instruction a
+// wave issues is time the matrix pipe of that SIMD does not get.
+template <int TW, int KS, int BK, bool SQ, bool OFF32>
 __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 {
     constexpr int BM = 32 * TW, BN = 32 * TW;
     constexpr int NT = 256 * KS;        // KS groups of 4 waves split the k-steps of every K-tile
     constexpr int NQ = BM * BK / NT;    // elements of each operand tile per thread
-    constexpr int ASZ = 2 * BK * (BM + LDP), BSZ = 2 * BK * (BN + LDP);
+    constexpr int LDA = BM + LDP, LDB = BN + LDP;
+    constexpr int ASZ = 2 * BK * LDA, BSZ = 2 * BK * LDB;
     __shared__ double lds[ASZ + BSZ];  // one array: the KS == 2 epilogue reuses all of it
-    double (*As)[BK][BM + LDP] = reinterpret_cast<double (*)[BK][BM + LDP]>(lds);
-    double (*Bs)[BK][BN + LDP] = reinterpret_cast<double (*)[BK][BN + LDP]>(lds + ASZ);
+    typedef typename std::conditional<OFF32, unsigned, long>::type off_t;  // byte offsets
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
     const int wm = wave >> 1, wn = wave & 1;
@@ -46,29 +54,34 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
     const int kb = g.kchunk ? (int)blockIdx.z * g.kchunk : 0;
     const int kend = g.kchunk ? (kb + g.kchunk < g.k ? kb + g.kchunk : g.k) : g.k;
 
-    // element -> (row-in-tile, k) mapping follows the contiguous dimension of each operand; per
-    // element: a running pointer, its k index inside a K-tile and whether its row is in range
+    // element -> (row-in-tile, k) mapping follows the contiguous dimension of each operand
     const bool a_kfast = (g.sa_k == 1);
     const bool b_kfast = (g.sb_k == 1);
-    const double* pa[NQ];
-    const double* pb[NQ];
-    int ak[NQ], bk[NQ], al[NQ], bl[NQ];  // k index; LDS offset of the element
-    unsigned okm = 0, okn = 0;
+    const char* Ab = reinterpret_cast<const char*>(g.A + (long)m0 * g.sa_m + (long)kb * g.sa_k);
+    const char* Bb = reinterpret_cast<const char*>(g.B + (long)n0 * g.sb_n + (long)kb * g.sb_k);
+    off_t oa[NQ], ob[NQ];
+    int ak[NQ], bk[NQ];
+    double* al[NQ];  // where the element goes in buffer 0 of its LDS tile
+    double* bl[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int e = tid + q * NT;
         int am, bn;
         if (a_kfast) { ak[q] = e % BK; am = e / BK; } else { am = e % BM; ak[q] = e / BM; }
         if (b_kfast) { bk[q] = e % BK; bn = e / BK; } else { bn = e % BN; bk[q] = e / BN; }
-        const bool oa = m0 + am < g.m, ob = n0 + bn < g.n;
-        okm |= (oa ? 1u : 0u) << q;
-        okn |= (ob ? 1u : 0u) << q;
-        pa[q] = g.A + (long)(oa ? m0 + am : 0) * g.sa_m + (long)(kb + ak[q]) * g.sa_k;
-        pb[q] = g.B + (long)(ob ? n0 + bn : 0) * g.sb_n + (long)(kb + bk[q]) * g.sb_k;
-        al[q] = ak[q] * (BM + LDP) + am;
-        bl[q] = bk[q] * (BN + LDP) + bn;
+        // rows beyond the matrix read the tile's first row: they only feed output rows that are
+        // never stored
+        const long ea = (long)(m0 + am < g.m ? am : 0) * g.sa_m + (long)ak[q] * g.sa_k;
+        const long eb = (long)(n0 + bn < g.n ? bn : 0) * g.sb_n + (long)bk[q] * g.sb_k;
+        oa[q] = (off_t)(ea * 8);
+        ob[q] = (off_t)(eb * 8);
+        al[q] = lds + ak[q] * LDA + am;
+        bl[q] = lds + ASZ + bk[q] * LDB + bn;
     }
-    const long da = (long)BK * g.sa_k, db = (long)BK * g.sb_k;
+    const long da = (long)BK * g.sa_k * 8, db = (long)BK * g.sb_k * 8;
+    // this lane's operands of k-step 0 in buffer 0
+    const double* ar = lds + (4 * ks + (lane >> 4)) * LDA + wm * 16 * TW + (lane & 15);
+    const double* br = lds + ASZ + (4 * ks + (lane >> 4)) * LDB + wn * 16 * TW + (lane & 15);
 
     double4_t acc[TW][TW];
 #pragma unroll
@@ -76,46 +89,52 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 #pragma unroll
         for (int j = 0; j < TW; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
+    // A tile travels global memory -> registers (raw values, nothing depends on them until the
+    // next iteration, so the loads stay in flight behind a whole K-tile of MFMAs) -> LDS (squared
+    // there when asked).  Interior K-tiles load without any mask; only the last one checks k.
     double ra[NQ], rb[NQ];
-    auto load_tile = [&](int k0) {  // tile starting at k0 -> registers; advances the pointers
+    auto load_tile = [&](int k0) {  // tile starting at k0 -> registers; advances the bases
+        if (k0 + BK <= kend) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const double v = (((okm >> q) & 1u) && k0 + ak[q] < kend) ? *pa[q] : 0.0;
-            ra[q] = g.sqA ? v * v : v;
-            const double u = (((okn >> q) & 1u) && k0 + bk[q] < kend) ? *pb[q] : 0.0;
-            rb[q] = g.sqB ? u * u : u;
-            pa[q] += da;
-            pb[q] += db;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        double* as = &As[buf][0][0];
-        double* bs = &Bs[buf][0][0];
+            for (int q = 0; q < NQ; ++q) {
+                ra[q] = *reinterpret_cast<const double*>(Ab + oa[q]);
+                rb[q] = *reinterpret_cast<const double*>(Bb + ob[q]);
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            as[al[q]] = ra[q];
-            bs[bl[q]] = rb[q];
+            for (int q = 0; q < NQ; ++q) {
+                ra[q] = (k0 + ak[q] < kend) ? *reinterpret_cast<const double*>(Ab + oa[q]) : 0.0;
+                rb[q] = (k0 + bk[q] < kend) ? *reinterpret_cast<const double*>(Bb + ob[q]) : 0.0;
+            }
         }
+        Ab += da;
+        Bb += db;
     };
-
-    // double-buffered LDS: ONE barrier per K-tile; tile t + 1 is written to the other buffer
-    // while the MFMAs of tile t read this one, tile t + 2 is in flight from global memory
-    load_tile(kb);
-    store_tile(0);
-    if (kb + BK < kend) load_tile(kb + BK);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = kb; k0 < kend; k0 += BK) {
-        if (k0 + BK < kend) store_tile(buf ^ 1);
+    // One K-tile: tile t + 1 goes from registers to the other buffer, tile t + 2 is requested,
+    // the MFMAs of tile t read buffer `buf` (a compile-time constant: every LDS address of the
+    // loop is a loop-invariant register plus an immediate).
+    auto k_tile = [&](auto bufc, int k0) {
+        constexpr int buf = decltype(bufc)::value;
+        if (k0 + BK < kend) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                double va = ra[q], vb = rb[q];
+                if constexpr (SQ) {
+                    va = g.sqA ? va * va : va;
+                    vb = g.sqB ? vb * vb : vb;
+                }
+                al[q][(buf ^ 1) * BK * LDA] = va;
+                bl[q][(buf ^ 1) * BK * LDB] = vb;
+            }
+        }
         if (k0 + 2 * BK < kend) load_tile(k0 + 2 * BK);
 #pragma unroll
-        for (int kk = 4 * ks; kk < BK; kk += 4 * KS) {
-            const int kr = kk + (lane >> 4);
+        for (int s = 0; s < BK / (4 * KS); ++s) {
             double a[TW], b[TW];
 #pragma unroll
-            for (int i = 0; i < TW; ++i) a[i] = As[buf][kr][wm * 16 * TW + i * 16 + (lane & 15)];
+            for (int i = 0; i < TW; ++i) a[i] = ar[buf * BK * LDA + 4 * KS * s * LDA + i * 16];
 #pragma unroll
-            for (int j = 0; j < TW; ++j) b[j] = Bs[buf][kr][wn * 16 * TW + j * 16 + (lane & 15)];
+            for (int j = 0; j < TW; ++j) b[j] = br[buf * BK * LDB + 4 * KS * s * LDB + j * 16];
 #pragma unroll
             for (int i = 0; i < TW; ++i)
 #pragma unroll
@@ -123,7 +142,24 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
-        buf ^= 1;
+    };
+
+    load_tile(kb);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double va = ra[q], vb = rb[q];
+        if constexpr (SQ) {
+            va = g.sqA ? va * va : va;
+            vb = g.sqB ? vb * vb : vb;
+        }
+        al[q][0] = va;
+        bl[q][0] = vb;
+    }
+    if (kb + BK < kend) load_tile(kb + BK);
+    __syncthreads();
+    for (int k0 = kb; k0 < kend; k0 += 2 * BK) {
+        k_tile(std::integral_constant<int, 0>{}, k0);
+        if (k0 + BK < kend) k_tile(std::integral_constant<int, 1>{}, k0 + BK);
     }
 
     if constexpr (KS == 2) {
@@ -196,6 +232,32 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const double* p
     *c = v;
 }
 
+// Picks the instantiation: squaring code only when an operand is squared; 32-bit lane offsets when
+// every element of a tile lies within 2^31 bytes after the tile's first one.
+template <int TW, int KS, int BK>
+static int launch_gemm(const GemmDesc& g, dim3 grid, hipStream_t st)
+{
+    constexpr int BM = 32 * TW;
+    const bool sq = g.sqA || g.sqB;
+    const long lim = (1L << 28) - 1;  // elements
+    const bool off32 = !getenv("LOCUS_HIP_GEMM_OFF64") && g.sa_m >= 0 && g.sa_k >= 0 &&
+                       g.sb_n >= 0 && g.sb_k >= 0 &&
+                       (BM - 1) * g.sa_m + (BK - 1) * g.sa_k <= lim &&
+                       (BM - 1) * g.sb_n + (BK - 1) * g.sb_k <= lim;
+    auto go = [&](auto kern) {
+        if (sizeof(double) * 2 * BK * 2 * (BM + LDP) > 64 * 1024)
+            LOCUS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 0));
+        hipLaunchKernelGGL(kern, grid, dim3(256 * KS), 0, st, g);
+        return 0;
+    };
+    if (sq)
+        return off32 ? go(gemm_f64_kernel<TW, KS, BK, true, true>)
+                     : go(gemm_f64_kernel<TW, KS, BK, true, false>);
+    return off32 ? go(gemm_f64_kernel<TW, KS, BK, false, true>)
+                 : go(gemm_f64_kernel<TW, KS, BK, false, false>);
+}
+
 int gemm_f64(const GemmDesc& g_in, hipStream_t st)
 {
     if (g_in.m <= 0 || g_in.n <= 0) return 0;
@@ -230,16 +292,13 @@ int gemm_f64(const GemmDesc& g_in, hipStream_t st)
     }
     const char* tw = getenv("LOCUS_HIP_GEMM_TW");
     const char* ksv = getenv("LOCUS_HIP_GEMM_KS");
+    int rc = 0;
     if (tw && tw[0] == '4') {
         dim3 grid((g.m + 127) / 128, (g.n + 127) / 128);
-        if (ksv && ksv[0] == '2') {
-            auto kern = gemm_f64_kernel<4, 2, 16>;
-            LOCUS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 0));
-            hipLaunchKernelGGL(kern, grid, dim3(512), 0, st, g);
-        } else {
-            hipLaunchKernelGGL((gemm_f64_kernel<4, 1, 16>), grid, dim3(256), 0, st, g);
-        }
+        if (ksv && ksv[0] == '2')
+            rc = launch_gemm<4, 2, 16>(g, grid, st);
+        else
+            rc = launch_gemm<4, 1, 16>(g, grid, st);
     } else {
         dim3 grid((g.m + 63) / 64, (g.n + 63) / 64, nz);
         const long tiles = (long)grid.x * grid.y * nz;
@@ -250,17 +309,14 @@ int gemm_f64(const GemmDesc& g_in, hipStream_t st)
         // at most ~one output tile per CU: the K loop is long and serial, a deeper K-tile halves
         // its barriers (82 KB of LDS: one workgroup per CU, which is all there is anyway)
         const bool deep = bkv ? (bkv[0] == '3') : (tiles <= 384);
-        if (split && deep) {
-            auto kern = gemm_f64_kernel<2, 2, 32>;
-            LOCUS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 0));
-            hipLaunchKernelGGL(kern, grid, dim3(512), 0, st, g);
-        } else if (split) {
-            hipLaunchKernelGGL((gemm_f64_kernel<2, 2, 16>), grid, dim3(512), 0, st, g);
-        } else {
-            hipLaunchKernelGGL((gemm_f64_kernel<2, 1, 16>), grid, dim3(256), 0, st, g);
-        }
+        if (split && deep)
+            rc = launch_gemm<2, 2, 32>(g, grid, st);
+        else if (split)
+            rc = launch_gemm<2, 2, 16>(g, grid, st);
+        else
+            rc = launch_gemm<2, 1, 16>(g, grid, st);
     }
+    if (rc) return rc;
     LOCUS_HIP_CHECK(hipGetLastError());
     if (part != nullptr) {
         const long mn = (long)g_in.m * g_in.n;

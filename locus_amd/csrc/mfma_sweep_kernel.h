@@ -398,6 +398,13 @@ mfma_sweep_kernel(const MfmaSweepParams P)
         __syncthreads();  // E2
     } else {
         // =========================== chain role ===========================================
+        // The chain shares its SIMD with matrix wave XW: its instructions go first when both are
+        // ready (block 20.1k -> 19.1k cycles).  Running the two one after the other instead (cross
+        // correction first, XW's stream after the chain) was measured slower: the chain alone
+        // takes 11.6k cycles per block here, and 11.6k + 9.2k of MFMA exceeds the 19.7k of the
+        // other three SIMDs, while interleaved the chain's LDS and store instructions overlap
+        // with the MFMAs.
+        __builtin_amdgcn_s_setprio(3);
         double c_scale = 0.0, c_hinv = 0.0, c_cst = 0.0, c_s2 = 0.0;
         if (cvalid) {
             c_scale = P.scale[kc];
