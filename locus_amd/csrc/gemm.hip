@@ -30,13 +30,27 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int LDP = 17;
 
-// SQ: some operand is squared on its way to LDS (g.sqA / g.sqB say which); OFF32: the elements of
-// a tile lie within 2^31 bytes after the tile's first element (non-negative strides), so an
-// element's address is a wave-uniform 64-bit base plus a 32-bit lane offset: the base advances
-// on the scalar unit and the K loop has no vector address arithmetic at all.  On gfx950 the fp64
-// MFMA runs on the SIMD's fp64 vector lanes (same 78.6 TFLOP/s peak): every vector instruction a
-// wave issues is time the matrix pipe of that SIMD does not get.
-template <int TW, int KS, int BK, bool SQ, bool OFF32>
+// One element of an operand tile.  OFF32: the address is a wave-uniform 64-bit base plus a 32-bit
+// lane offset, which is exactly a raw buffer load (base in the scalar resource, `offen` lane
+// offset); the resource is rebuilt from the running base on the scalar unit.
+template <bool OFF32, class O>
+__device__ __forceinline__ double ld_elem(const char* base, O off)
+{
+    if constexpr (OFF32) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(base), 0, 0x7fffffff, 0x00020000 /* 32-bit data format, gfx9 */);
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    } else {
+        return *reinterpret_cast<const double*>(base + off);
+    }
+}
+
+// SQ: 0 = no operand is squared on its way to LDS, 1 = A is, 2 = g.sqA / g.sqB say which.
+// OFF32: the elements of a tile lie within 2^31 bytes after the tile's first element (non-negative
+// strides), so the K loop has no vector address arithmetic at all: the bases advance on the scalar
+// unit.  On gfx950 the fp64 MFMA runs on the SIMD's fp64 vector lanes (same 78.6 TFLOP/s peak):
+// every vector instruction a wave issues is time the matrix pipe of that SIMD does not get.
+template <int TW, int KS, int BK, int SQ, bool OFF32>
 __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 {
     constexpr int BM = 32 * TW, BN = 32 * TW;
@@ -97,14 +111,14 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
         if (k0 + BK <= kend) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                ra[q] = *reinterpret_cast<const double*>(Ab + oa[q]);
-                rb[q] = *reinterpret_cast<const double*>(Bb + ob[q]);
+                ra[q] = ld_elem<OFF32>(Ab, oa[q]);
+                rb[q] = ld_elem<OFF32>(Bb, ob[q]);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                ra[q] = (k0 + ak[q] < kend) ? *reinterpret_cast<const double*>(Ab + oa[q]) : 0.0;
-                rb[q] = (k0 + bk[q] < kend) ? *reinterpret_cast<const double*>(Bb + ob[q]) : 0.0;
+                ra[q] = (k0 + ak[q] < kend) ? ld_elem<OFF32>(Ab, oa[q]) : 0.0;
+                rb[q] = (k0 + bk[q] < kend) ? ld_elem<OFF32>(Bb, ob[q]) : 0.0;
             }
         }
         Ab += da;
@@ -119,7 +133,8 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 double va = ra[q], vb = rb[q];
-                if constexpr (SQ) {
+                if constexpr (SQ == 1) va = va * va;
+                if constexpr (SQ == 2) {
                     va = g.sqA ? va * va : va;
                     vb = g.sqB ? vb * vb : vb;
                 }
@@ -148,7 +163,8 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         double va = ra[q], vb = rb[q];
-        if constexpr (SQ) {
+        if constexpr (SQ == 1) va = va * va;
+        if constexpr (SQ == 2) {
             va = g.sqA ? va * va : va;
             vb = g.sqB ? vb * vb : vb;
         }
@@ -238,7 +254,6 @@ template <int TW, int KS, int BK>
 static int launch_gemm(const GemmDesc& g, dim3 grid, hipStream_t st)
 {
     constexpr int BM = 32 * TW;
-    const bool sq = g.sqA || g.sqB;
     const long lim = (1L << 28) - 1;  // elements
     const bool off32 = !getenv("LOCUS_HIP_GEMM_OFF64") && g.sa_m >= 0 && g.sa_k >= 0 &&
                        g.sb_n >= 0 && g.sb_k >= 0 &&
@@ -251,11 +266,15 @@ static int launch_gemm(const GemmDesc& g, dim3 grid, hipStream_t st)
         hipLaunchKernelGGL(kern, grid, dim3(256 * KS), 0, st, g);
         return 0;
     };
-    if (sq)
-        return off32 ? go(gemm_f64_kernel<TW, KS, BK, true, true>)
-                     : go(gemm_f64_kernel<TW, KS, BK, true, false>);
-    return off32 ? go(gemm_f64_kernel<TW, KS, BK, false, true>)
-                 : go(gemm_f64_kernel<TW, KS, BK, false, false>);
+    const int sq = (g.sqA && !g.sqB) ? 1 : ((g.sqA || g.sqB) ? 2 : 0);
+    if (sq == 1)
+        return off32 ? go(gemm_f64_kernel<TW, KS, BK, 1, true>)
+                     : go(gemm_f64_kernel<TW, KS, BK, 1, false>);
+    if (sq == 2)
+        return off32 ? go(gemm_f64_kernel<TW, KS, BK, 2, true>)
+                     : go(gemm_f64_kernel<TW, KS, BK, 2, false>);
+    return off32 ? go(gemm_f64_kernel<TW, KS, BK, 0, true>)
+                 : go(gemm_f64_kernel<TW, KS, BK, 0, false>);
 }
 
 int gemm_f64(const GemmDesc& g_in, hipStream_t st)
