@@ -8,15 +8,27 @@
 //
 // Tiling: (32 TW) x (32 TW) block tile, K-tile BK, waves owning a quadrant as TW x TW MFMA tiles.
 // LDS is double-buffered: ONE barrier per K-tile, tile t + 1 is written to the other buffer while
-// the MFMAs of tile t read this one and tile t + 2 is in flight from global memory (register
-// prefetch through running pointers).  LDS rows are padded by 16 doubles so that the two 32-lane
-// halves of a ds_read_b64 fall on disjoint banks.  KS = 2: two groups of 4 waves split the k-steps
-// of every K-tile and add their partial tiles through LDS at the end, so that even a workgroup
-// that has its CU to itself runs two waves per SIMD.  Shipped: TW = 2 (64 x 64), KS = 2, BK = 16
-// (74 registers, 41 KB of LDS), BK = 32 when there is at most about one output tile per CU.
-// Measured on MI355X (scripts/perf_gemm.py): 46 TFLOP/s on the C3 mat_x_m1 (TW = 4, 128 x 128,
-// one workgroup per CU: 29 TFLOP/s, kept behind LOCUS_HIP_GEMM_TW=4 for experiments;
-// LOCUS_HIP_GEMM_KS / LOCUS_HIP_GEMM_BK override the other two choices).
+// the MFMAs of tile t read this one and tile t + 2 is in flight from global memory (raw values in
+// registers; squaring, when asked, happens on the way to LDS one K-tile later, so nothing waits
+// for a load inside the K-tile that issued it).  LDS rows are padded by 17 doubles (odd: the
+// transposing stores of a k-contiguous operand spread over the banks).  KS = 2: two groups of 4
+// waves split the k-steps of every K-tile and add their partial tiles through LDS at the end.
+//
+// The K loop has NO vector ALU instruction.  On gfx950 the fp64 MFMA executes on the SIMD's fp64
+// vector lanes (matrix and vector fp64 peaks are the same 78.6 TFLOP/s), so every VALU instruction
+// any wave of the SIMD issues -- address arithmetic, masks, selects -- is time its matrix pipe
+// does not get.  Hence: tile elements are raw buffer loads (wave-uniform 64-bit base in the scalar
+// resource, advanced with s_add; loop-invariant 32-bit lane offsets), the two LDS buffers are
+// compile-time constants (the loop is unrolled by two: every LDS address is a loop-invariant
+// register plus an immediate), interior K-tiles carry no k mask, rows beyond the matrix read the
+// tile's first row instead of being masked (they only feed output rows that are never stored),
+// and squaring is compiled in only when asked.  Removing ~28 VALU instructions per 8 MFMAs took
+// the C3 init product from 46 to 58 TFLOP/s.
+// Shipped: TW = 2 (64 x 64), KS = 2, BK = 16 (41 KB of LDS, three workgroups per CU), BK = 32 when
+// there is at most about one output tile per CU.  Measured on MI355X (scripts/perf_gemm.py):
+// 58.3 TFLOP/s (74 % of peak) on the C3 mat_x_m1, 49-50 on the C2 coreBatch products, 43-46 on
+// the C4 X^2 products.  TW = 4 (128 x 128, one workgroup per CU) stays behind LOCUS_HIP_GEMM_TW=4
+// for experiments; LOCUS_HIP_GEMM_KS / _BK / _SPLITK / _OFF64 override the other choices.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>

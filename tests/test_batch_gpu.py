@@ -22,7 +22,7 @@ def test_batch_matches_oracle(oracle, hip, variant, shape):
 # (8 and 2 slices of k, ragged last slice, partial products summed by the reduce kernel)
 @pytest.mark.parametrize("m,n,k", [(64, 64, 16), (70, 33, 19), (1, 1, 1), (200, 130, 257),
                                    (130, 70, 9001), (64, 64, 2049)])
-@pytest.mark.parametrize("layout", ["nn", "tn", "nt"])
+@pytest.mark.parametrize("layout", ["nn", "tn", "nt", "tt"])
 def test_gemm_f64(hip, m, n, k, layout):
     import torch
     from locus_amd import device as dv
@@ -44,6 +44,29 @@ def test_gemm_f64(hip, m, n, k, layout):
     Ct2 = torch.empty((m, n), dtype=torch.float64, device=dev)
     dv.gemm(m, n, k, At, sa_m, sa_k, Bt, sb_k, sb_n, Ct2, n, 1, sqA=True)
     np.testing.assert_allclose(Ct2.cpu().numpy(), (A * A) @ B, rtol=1e-12, atol=1e-12 * k ** 0.5)
+    # the run-time squaring flags (B alone, both operands) are a separate instantiation
+    dv.gemm(m, n, k, At, sa_m, sa_k, Bt, sb_k, sb_n, Ct2, n, 1, sqB=True)
+    np.testing.assert_allclose(Ct2.cpu().numpy(), A @ (B * B), rtol=1e-12, atol=1e-12 * k ** 0.5)
+    dv.gemm(m, n, k, At, sa_m, sa_k, Bt, sb_k, sb_n, Ct2, n, 1, sqA=True, sqB=True)
+    np.testing.assert_allclose(Ct2.cpu().numpy(), (A * A) @ (B * B), rtol=1e-12, atol=1e-12 * k ** 0.5)
+
+
+@pytest.mark.parametrize("m,n,k", [(70, 33, 19), (200, 130, 257)])
+def test_gemm_f64_negative_stride(hip, m, n, k):
+    """A negative stride takes the instantiation with 64-bit lane offsets (the default one
+    addresses a tile as scalar base + unsigned 32-bit offset): rows of A walked backwards."""
+    import torch
+    from locus_amd import device as dv
+    rng = np.random.default_rng(m * n + k)
+    A = rng.normal(size=(m, k)); B = rng.normal(size=(k, n))
+    dev = torch.device("cuda:0")
+    At = torch.from_numpy(A.copy()).to(dev)
+    Bt = torch.from_numpy(B.copy()).to(dev)
+    Ct = torch.empty((m, n), dtype=torch.float64, device=dev)
+    dv.gemm(m, n, k, At[m - 1], -k, 1, Bt, n, 1, Ct, n, 1)
+    np.testing.assert_allclose(Ct.cpu().numpy(), A[::-1] @ B, rtol=1e-12, atol=1e-12 * k ** 0.5)
+    dv.gemm(m, n, k, At[m - 1], -k, 1, Bt, n, 1, Ct, n, 1, sqA=True)
+    np.testing.assert_allclose(Ct.cpu().numpy(), (A * A)[::-1] @ B, rtol=1e-12, atol=1e-12 * k ** 0.5)
 
 
 def test_pack_transpose_rows_helpers(hip):
