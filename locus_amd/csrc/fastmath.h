@@ -33,6 +33,33 @@ __device__ __forceinline__ double exp_nonpos(double x)
     return __builtin_ldexp(p, (int)k);
 }
 
+// The same function with a SHORT dependent path, for the chain wave that runs alone on its SIMD
+// (mfma_sweep1_kernel.h: there every dependent fp64 instruction costs its full ~8 cycle latency):
+// p(r) = 1 + r q(r), q of degree 11 in Estrin form (pairs, then r^2, then r^4) -- 14 instructions,
+// 5 dependent levels after r instead of 13.  The final 1 + r q keeps the last rounding where
+// Horner has it: max error over [-745, 0] 2.5 ulp against 2.3 ulp for exp_nonpos (measured
+// against long double, 2 * 10^7 points).
+__device__ __forceinline__ double exp_nonpos_short(double x)
+{
+    x = (x < -800.0) ? -800.0 : x;  // a select, not fmax: see exp_nonpos
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    const double r2 = r * r;
+    const double q0 = fma(r, 0.5, 1.0);
+    const double q1 = fma(r, 4.16666666666666666667e-02, 1.66666666666666666667e-01);
+    const double q2 = fma(r, 1.38888888888888888889e-03, 8.33333333333333333333e-03);
+    const double q3 = fma(r, 2.48015873015873015873e-05, 1.98412698412698412698e-04);
+    const double q4 = fma(r, 2.75573192239858906526e-07, 2.75573192239858906526e-06);
+    const double q5 = fma(r, 2.08767569878680989792e-09, 2.50521083854417187751e-08);
+    const double r4 = r2 * r2;
+    const double s0 = fma(q1, r2, q0);
+    const double s1 = fma(q3, r2, q2);
+    const double s2 = fma(q5, r2, q4);
+    const double q = fma(fma(s2, r4, s1), r4, s0);
+    return __builtin_ldexp(fma(r, q, 1.0), (int)k);
+}
+
 // num / den for den in [1, 2], num in [0, 1]: v_rcp_f64 + two Newton steps + one residual
 // correction (no scaling / fix-up needed in this range).
 __device__ __forceinline__ double div_1to2(double num, double den)

@@ -12,6 +12,7 @@ namespace locus {
 int launch_mfma_sweep_t2(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
 int launch_mfma_sweep1_c1(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
 int launch_mfma_sweep1_c2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c3(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
 
 // ---------------------------------------------------------------------------
 // Block packing for mfma_sweep1_kernel (look-ahead of L blocks, NW = CS * 6 row groups).  One
@@ -249,8 +250,9 @@ int mfma1_kt_for(int64_t n, int CS)
 #define LOCUS_KT_ITEM(k) k,
     static const int kts1[] = {LOCUS_MFMA_KTS_T1(LOCUS_KT_ITEM) 0};
     static const int kts2[] = {LOCUS_MFMA1_KTS_C2(LOCUS_KT_ITEM) 0};
+    static const int kts3[] = {LOCUS_MFMA1_KTS_C3(LOCUS_KT_ITEM) 0};
 #undef LOCUS_KT_ITEM
-    for (const int* kt = (CS == 1) ? kts1 : kts2; *kt; ++kt)
+    for (const int* kt = (CS == 1) ? kts1 : (CS == 2 ? kts2 : kts3); *kt; ++kt)
         if ((int64_t)CS * 6 * 16 * *kt >= n) return *kt;
     return 0;
 }
@@ -258,9 +260,10 @@ int mfma1_kt_for(int64_t n, int CS)
 // doubles of the mfma_sweep1_kernel layout for `nblk` blocks (largest look-ahead, both CS)
 static size_t mfma1_layout_doubles(int64_t n, size_t nblk, int cus)
 {
-    const int kt1 = mfma1_kt_for(n, 1), kt2 = mfma1_kt_for(n, 2);
+    const int kt1 = mfma1_kt_for(n, 1), kt2 = mfma1_kt_for(n, 2), kt3 = mfma1_kt_for(n, 3);
     const size_t nit = nblk + 5;
-    const size_t rows_pad = std::max((size_t)6 * 16 * kt1, (size_t)2 * 6 * 16 * kt2);
+    const size_t rows_pad = std::max(std::max((size_t)6 * 16 * kt1, (size_t)2 * 6 * 16 * kt2),
+                                     (size_t)3 * 6 * 16 * kt3);
     return nit * rows_pad * 32 + 2048      // XS (+ read-ahead slack)
            + nit * 256                     // cg
            + 4 * (nit + 1) * 256           // ax, lags 1..4
@@ -435,24 +438,35 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
             LOCUS_HIP_CHECK(hipMemsetAsync(xflag, 0, sizeof(int) * (size_t)mp.ntiles * CS * 32, st));
         }
         dim3 grid((unsigned)(((mp.ntiles + 7) / 8) * 8 * CS));
-        const int rc = (CS == 1) ? launch_mfma_sweep1_c1(mp, KT, grid, st)
-                                 : launch_mfma_sweep1_c2(mp, KT, grid, st);
+        const int rc = (CS == 1)   ? launch_mfma_sweep1_c1(mp, KT, grid, st)
+                       : (CS == 2) ? launch_mfma_sweep1_c2(mp, KT, grid, st)
+                                   : launch_mfma_sweep1_c3(mp, KT, grid, st);
         if (rc) return rc;
     }
     return 0;
 }
 
-// row-split cluster size for `tiles` tiles of 16 responses: 2 when every member of every cluster
-// fits on the chip at once and n is covered, else 1.  LOCUS_HIP_MFMA_CS overrides (1 or 2).
+// Row-split cluster size for `tiles` tiles of 16 responses.  One workgroup per tile while its two
+// matrix waves per SIMD have less work per block than the chain (a wave issues 8 KT MFMAs of 64
+// cycles per block: KT <= 4 is <= 4096 cycles against a chain of ~5600; C2, n = 200: 3.31 ms with
+// one workgroup, 3.66 with two).  Otherwise 2 when the members of every cluster fit on the chip at
+// once.  3 is instantiated and tested but not chosen: at n = 1000 the matrix waves get lighter
+// (5260 cycles per block against 7660) and the helper wave, which shares its SIMD's vector ALU
+// with the chain, becomes the limit (10.97 ms against 10.99).  LOCUS_HIP_MFMA_CS overrides (1, 2, 3).
 static int choose_cs(int n, int tiles)
 {
     int want = 0;
     if (const char* e = getenv("LOCUS_HIP_MFMA_CS")) want = atoi(e);
     if (want == 1) return 1;
     const int cus = device_cus();
-    const bool fits2 = mfma1_kt_for(n, 2) > 0 && cus >= 16;
-    if (want == 2) return fits2 ? 2 : 1;
-    return (fits2 && ((tiles + 7) / 8) * 8 * 2 <= cus) ? 2 : 1;
+    const int t8 = ((tiles + 7) / 8) * 8;
+    if (want == 2 || want == 3) {
+        const bool ok = mfma1_kt_for(n, want) > 0 && cus >= 8 * want;
+        return ok ? want : 1;
+    }
+    const int kt1 = mfma1_kt_for(n, 1), kt2 = mfma1_kt_for(n, 2);
+    if (kt1 > 0 && kt1 <= 4) return 1;
+    return (kt2 > 0 && t8 * 2 <= cus) ? 2 : 1;
 }
 
 // cfg: C = T (tiles of 16 responses per workgroup; 0 = plan by d), G = KT (16-row tiles per matrix
@@ -469,8 +483,9 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
         return LOCUS_HIP_EINVAL;
     }
     if (cfg.C == 1) {  // one tile per cluster: mfma_sweep1_kernel, S = workgroups per cluster
-        // S = workgroups per cluster (1, 2); 0 = chosen from d; anything else (legacy) = 1
-        const int CS = (cfg.S == 2) ? 2 : (cfg.S == 0 ? choose_cs(prm.n, (prm.d + 15) / 16) : 1);
+        // S = workgroups per cluster (1, 2, 3); 0 = chosen from d; anything else (legacy) = 1
+        const int CS = (cfg.S == 2 || cfg.S == 3) ? cfg.S
+                                                  : (cfg.S == 0 ? choose_cs(prm.n, (prm.d + 15) / 16) : 1);
         const int KT = cfg.G > 0 ? cfg.G : mfma1_kt_for(prm.n, CS);
         return pack_and_launch1(prm, CS, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
     }

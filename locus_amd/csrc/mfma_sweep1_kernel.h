@@ -395,56 +395,158 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 const double* sc_b = scl + (b & 1) * 32;      // wave-uniform addresses: broadcast reads
                 const double* cg_b = gram + (b & 1) * 256;
 
-                double corr[kBlk];
+                // The dependent path of a step is cut to: dot -> dot^2 -> a -> exp -> 1 + e -> divide
+                // -> dot of the NEXT step (one FMA).  With
+                //     a_t = cB_t - cA dot_t^2,            cA = cfac scale^2 hinv,  cB_t = cfac (lod_t + cst)
+                //     dot_{t+1} = pre_{t+1} - (g m_t) gam_t,
+                //     pre_{t+1} = u_{t+1} + xtx_{t+1} bo_{t+1} + sum_{s<t} g[s][t+1] d_s + g[t][t+1] bo_t,
+                // (g = column t of the block's Gram matrix, d_s = bo_s - m_s gam_s) everything but
+                // the last FMA is known before gam_t is: m, beta, delta, the corrections of the
+                // later steps and the LDS traffic of step t are issued inside step t + 1, in the
+                // latency gaps of its chain (one scheduling region per step, fenced right after
+                // the next dot).  coreLoop.cpp:42-48, re-associated (rounding-level differences).
+                const double cA = cfac * c_scale * c_scale * c_hinv;
+                const double cC = cfac * c_cst;
+                double corr[kBlk];  // corr[t2] = sum over the steps s whose delta is applied of g[s][t2] d_s
 #pragma unroll
                 for (int t = 0; t < kBlk; ++t) corr[t] = 0.0;
-                double u_c = gx_l[0], bo_c = bo_l[0];
+                double bo_c = bo_l[0];
                 double2 sc_c = *reinterpret_cast<const double2*>(sc_b);
-                __builtin_amdgcn_sched_barrier(0);
+                double dot = fma(sc_c.y, bo_c, gx_l[0]);
+                // step t - 1, finished but not yet written / applied
+                double m_p = 0.0, gam_p = 0.0, bo_p = 0.0;
+                // Gram columns of the steps t (even / odd): column t is requested in step t, gives
+                // g[t][t+1] at its end and the corrections of the later steps during step t + 1
+                double gc0[kBlk], gc1[kBlk];
+#pragma unroll
+                for (int t = 0; t < kBlk; ++t) gc0[t] = gc1[t] = 0.0;
+                // The compiler's scheduler puts the whole dependent chain first and everything
+                // else behind it (on the path); so the step is written as the chain's instructions
+                // one by one, each fenced together with the off-path work that fills its latency.
+#define LOCUS_FENCE() __builtin_amdgcn_sched_barrier(0)
+                LOCUS_FENCE();
                 sfor<kBlk>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
-                    // requests for step t + 1
-                    double u_n = 0.0, bo_n = 0.0;
+                    double (&gc)[kBlk] = (t & 1) ? gc1 : gc0;    // column t
+                    double (&gp)[kBlk] = (t & 1) ? gc0 : gc1;    // column t - 1
+                    double delta = 0.0, m = 0.0, bo_n = 0.0, gx_n = 0.0, base = 0.0, pre = 0.0, gm = 0.0;
                     double2 sc_n = make_double2(0.0, 0.0);
-                    if constexpr (t + 1 < kBlk) {
-                        u_n = gx_l[(t + 1) * 16];
+                    // corrections of the steps t + 2 + i by the delta of step t - 1
+                    auto corr_upd = [&](auto ic) {
+                        constexpr int t2 = t + 2 + decltype(ic)::value;
+                        if constexpr (t > 0 && t2 < kBlk) corr[t2] = fma(gp[t2], delta, corr[t2]);
+                    };
+                    using std::integral_constant;
+                    const double lod = sc_c.x;
+                    const double cB = fma(cfac, lod, cC);
+
+                    const double dd = dot * dot;
+                    if constexpr (t + 1 < kBlk) {   // requests for step t + 1
+                        // column t of the block's Gram matrix, entries t + 1 .. 15, as 16-byte pairs
+                        // (the pair that holds entry t + 1 may start at the zero diagonal entry)
+                        sfor<8 - ((t + 1) >> 1)>([&](auto c2) {
+                            constexpr int t2 = 2 * (((t + 1) >> 1) + decltype(c2)::value);
+                            const double2 g2 = *reinterpret_cast<const double2*>(cg_b + t * 16 + t2);
+                            gc[t2] = g2.x;
+                            gc[t2 + 1] = g2.y;
+                        });
                         bo_n = bo_l[(t + 1) * 16];
                         sc_n = *reinterpret_cast<const double2*>(sc_b + 2 * (t + 1));
+                        gx_n = gx_l[(t + 1) * 16];
                     }
-                    // column t of the block's Gram matrix, entries t + 1 .. 15, as 16-byte pairs
-                    // (the pair that holds entry t + 1 may start at the zero diagonal entry)
-                    double gcol[kBlk];
-                    sfor<8 - ((t + 1) >> 1)>([&](auto c2) {
-                        constexpr int t2 = 2 * (((t + 1) >> 1) + decltype(c2)::value);
-                        const double2 g2 = *reinterpret_cast<const double2*>(cg_b + t * 16 + t2);
-                        gcol[t2] = g2.x;
-                        gcol[t2 + 1] = g2.y;
-                    });
-                    const double lod = sc_c.x, xtx = sc_c.y;
-
-                    const double u = u_c + corr[t];
-                    const double dot = fma(xtx, bo_c, u);
-                    const double m = c_scale * dot;                            // coreLoop.cpp:42-43
-                    const double a = cfac * ((lod - m * m * c_hinv) + c_cst);  // :45-46
-                    const double e = exp_nonpos(-fabs(a));
-                    const double gmv = div_1to2((a >= 0.0) ? e : 1.0, 1.0 + e);
-                    const double bn = m * gmv;                                 // :48
-                    // inactive steps / responses: beta_old is staged as 0 and every operand of m
-                    // is 0, so delta = 0 without a select
-                    const double delta = bo_c - bn;
-                    sfor<kBlk - 1 - t>([&](auto c2) {
-                        constexpr int t2 = t + 1 + decltype(c2)::value;
-                        corr[t2] = fma(gcol[t2], delta, corr[t2]);
-                    });
-                    dl_w[t * 16] = delta;
-                    mg_w[t * 16] = m;
-                    mg_w[256 + t * 16] = gmv;
-                    if constexpr (CS == 1 && (t & 3) == 3) lds_publish(&prog, 16 * b + t + 1);
-                    u_c = u_n;
+                    LOCUS_FENCE();
+                    const double a = fma(-cA, dd, cB);                         // coreLoop.cpp:42-46
+                    if constexpr (t > 0) delta = fma(-m_p, gam_p, bo_p);       // :48, beta_old - beta_new
+                    LOCUS_FENCE();
+                    double x = -fabs(a);
+                    x = (x < -800.0) ? -800.0 : x;  // a select, not fmax: a NaN stays a NaN (fastmath.h)
+                    if constexpr (t > 0 && t + 1 < kBlk) corr[t + 1] = fma(gp[t + 1], delta, corr[t + 1]);
+                    m = c_scale * dot;
+                    LOCUS_FENCE();
+                    const double kf = __builtin_rint(x * 1.4426950408889634074);
+                    if constexpr (t > 0) {
+                        dl_w[(t - 1) * 16] = delta;
+                        mg_w[(t - 1) * 16] = m_p;
+                        mg_w[256 + (t - 1) * 16] = gam_p;
+                        if constexpr (CS == 1 && (t & 3) == 0) lds_publish(&prog, 16 * b + t);
+                    }
+                    LOCUS_FENCE();
+                    double r = fma(kf, -6.93147180369123816490e-01, x);
+                    corr_upd(integral_constant<int, 0>{});
+                    corr_upd(integral_constant<int, 1>{});
+                    LOCUS_FENCE();
+                    r = fma(kf, -1.90821492927058770002e-10, r);
+                    corr_upd(integral_constant<int, 2>{});
+                    corr_upd(integral_constant<int, 3>{});
+                    LOCUS_FENCE();
+                    // exp_nonpos_short (fastmath.h), inlined: the Estrin block issues back to back
+                    const double r2 = r * r;
+                    const double q0 = fma(r, 0.5, 1.0);
+                    const double q1 = fma(r, 4.16666666666666666667e-02, 1.66666666666666666667e-01);
+                    const double q2 = fma(r, 1.38888888888888888889e-03, 8.33333333333333333333e-03);
+                    const double q3 = fma(r, 2.48015873015873015873e-05, 1.98412698412698412698e-04);
+                    const double q4 = fma(r, 2.75573192239858906526e-07, 2.75573192239858906526e-06);
+                    const double q5 = fma(r, 2.08767569878680989792e-09, 2.50521083854417187751e-08);
+                    const double r4 = r2 * r2;
+                    const double s0 = fma(q1, r2, q0);
+                    const double s1 = fma(q3, r2, q2);
+                    const double s2 = fma(q5, r2, q4);
+                    const double qq = fma(fma(s2, r4, s1), r4, s0);
+                    const double pp = fma(r, qq, 1.0);
+                    LOCUS_FENCE();
+                    const double e = __builtin_ldexp(pp, (int)kf);
+                    corr_upd(integral_constant<int, 4>{});
+                    corr_upd(integral_constant<int, 5>{});
+                    LOCUS_FENCE();
+                    const double den = 1.0 + e;
+                    const double num = (a >= 0.0) ? e : 1.0;
+                    corr_upd(integral_constant<int, 6>{});
+                    LOCUS_FENCE();
+                    double rcp = __builtin_amdgcn_rcp(den);                    // div_1to2 (fastmath.h)
+                    corr_upd(integral_constant<int, 7>{});
+                    corr_upd(integral_constant<int, 8>{});
+                    LOCUS_FENCE();
+                    double tt = fma(-den, rcp, 1.0);
+                    corr_upd(integral_constant<int, 9>{});
+                    corr_upd(integral_constant<int, 10>{});
+                    LOCUS_FENCE();
+                    rcp = fma(tt, rcp, rcp);
+                    corr_upd(integral_constant<int, 11>{});
+                    corr_upd(integral_constant<int, 12>{});
+                    LOCUS_FENCE();
+                    tt = fma(-den, rcp, 1.0);
+                    corr_upd(integral_constant<int, 13>{});
+                    if constexpr (t + 1 < kBlk) base = fma(sc_n.y, bo_n, gx_n);
+                    LOCUS_FENCE();
+                    rcp = fma(tt, rcp, rcp);
+                    if constexpr (t + 1 < kBlk) {
+                        pre = fma(gc[t + 1], bo_c, corr[t + 1]);
+                        gm = gc[t + 1] * m;
+                    }
+                    LOCUS_FENCE();
+                    const double qv = num * rcp;
+                    if constexpr (t + 1 < kBlk) pre += base;
+                    LOCUS_FENCE();
+                    tt = fma(-den, qv, num);
+                    LOCUS_FENCE();
+                    const double gmv = fma(tt, rcp, qv);
+                    LOCUS_FENCE();
+                    dot = fma(-gm, gmv, pre);                                  // dot of step t + 1
+                    m_p = m;
+                    gam_p = gmv;
+                    bo_p = bo_c;
                     bo_c = bo_n;
                     sc_c = sc_n;
-                    __builtin_amdgcn_sched_barrier(0);
+                    LOCUS_FENCE();
                 });
+#undef LOCUS_FENCE
+                {
+                    const double delta = fma(-m_p, gam_p, bo_p);
+                    dl_w[15 * 16] = delta;
+                    mg_w[15 * 16] = m_p;
+                    mg_w[256 + 15 * 16] = gam_p;
+                    if constexpr (CS == 1) lds_publish(&prog, 16 * b + 16);
+                }
             }
             M1STAMP(1);
             if constexpr (CS > 1) {
@@ -557,20 +659,39 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     const unsigned tag = (unsigned)bn_blk + 1u;
                     const unsigned long long* gsrc =
                         xb_tile + (size_t)(bn_blk % kXRing) * CS * 512 + lane;
-                    for (int spin = 0;; ++spin) {
+                    // The granules were fetched one iteration ago and the wait of that iteration's
+                    // hand-over covered them: the check below must not wait for anything.  (Written
+                    // as one loop -- check, break, sleep, refetch -- the compiler put a vmcnt(0) in
+                    // front of the FIRST check as well, because the registers may come from the
+                    // refetch: ~1800 cycles per block waiting for the previous block's result stores.)
+                    auto tags_ok = [&]() {
                         bool ok = true;
 #pragma unroll
                         for (int e = 0; e < CS * 8; ++e) ok = ok && ((unsigned)(gv[e] >> 32) == tag);
-                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                        if (spin > (1 << 19)) {  // ~0.5 s: the partner is not running
-                            if (lane == 0) atomicOr(P.err, 4);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(4);
+                        return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+                    };
+                    if (!tags_ok()) {  // a partner is late: poll
+                        for (int spin = 0;; ++spin) {
+                            if (spin > (1 << 19)) {  // ~0.5 s: the partner is not running
+                                if (lane == 0) atomicOr(P.err, 4);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(4);
+#ifdef LOCUS_STAMPS
+                            tacc[7] += 1;  // refetches
+#endif
 #pragma unroll
-                        for (int e = 0; e < CS * 8; ++e)
-                            gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            for (int e = 0; e < CS * 8; ++e)
+                                gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+                            // pin: the wait for these loads is issued HERE, on the slow path, and
+                            // the registers leave it with nothing pending
+#pragma unroll
+                            for (int e = 0; e < CS * 8; ++e) asm volatile("" : "+v"(gv[e]));
+                            if (tags_ok()) break;
+                        }
                     }
+                    M1STAMP(3);
 #pragma unroll
                     for (int cm = 0; cm < CS; ++cm)   // member order: identical sums in every member
 #pragma unroll
@@ -642,6 +763,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     }
                 }
             }
+            M1STAMP(4);
             // ---- hand over what was requested: the ONE wait for global memory of this iteration.
             // Every store of the iteration comes after it (the memory counter is in order: a wait
             // for these loads behind the stores would also wait for the stores' write-through).
@@ -670,6 +792,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 for (int e = 0; e < CS * 8; ++e) asm volatile("" : "+v"(gv[e]));
             }
             __builtin_amdgcn_sched_barrier(0);
+            M1STAMP(5);
             if constexpr (CS > 1) {
                 // ---- publish this member's partial tile of block it - 1 ---------------------------
                 if (it >= 1 && it - 1 < P.nblk) {

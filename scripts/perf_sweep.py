@@ -73,7 +73,7 @@ def main():
         elif "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0 and cfg[1] == 1:
             import ctypes
             import os
-            cs_used = 2 if (cfg[2] == 2 or os.environ.get("LOCUS_HIP_MFMA_CS") == "2") else 1
+            cs_used = cfg[2] if cfg[2] in (2, 3) else int(os.environ.get("LOCUS_HIP_MFMA_CS", "1"))
             fn = getattr(ctypes.CDLL(_lib.LIB_PATH), f"locus_hip_diag_read_mfma1_stamps_c{cs_used}")
             nwg = min(4096, 2 * ((d + 15) // 16 + 8))
             buf = (ctypes.c_ulonglong * (32 * nwg))()
@@ -83,11 +83,15 @@ def main():
             roles = {0: ("matrix wave 0", ["B1-wait", "mfma", "gfin-wait", "corr(l>=2)", "follow+write"]),
                      1: ("matrix wave 5", ["B1-wait", "mfma"]),
                      2: ("chain", ["B1-wait", "run", "-", "next-G"]),
-                     3: ("helper", ["B1-wait", "reduce/xchg", "store/bol"])}
+                     3: ("helper", ["B1-wait", "sums", "stores", "granule-wait", "requests", "load-wait+handover", "-", "refetches"])}
             for ro, (nm, names) in roles.items():
                 med = np.median(a[:, ro, :len(names)], axis=0)
                 print(f"   ticks/block {nm:14s}: " + " ".join(f"{k}={v:.0f}" for k, v in zip(names, med))
                       + f" total={med.sum():.0f}")
+                if ro == 3:
+                    for pc in (10, 90):
+                        qv = np.percentile(a[:, ro, :len(names)], pc, axis=0)
+                        print(f"      helper p{pc}: " + " ".join(f"{k}={v:.0f}" for k, v in zip(names, qv)))
         elif "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0:
             import ctypes
             fn = getattr(ctypes.CDLL(_lib.LIB_PATH), f"locus_hip_diag_read_mfma_stamps_{cfg[1]}")

@@ -113,13 +113,14 @@ def test_two_sweeps_in_a_row_deterministic(hip):
 # S waves, KW4 16-row tiles per wave): ragged rows / responses / last block of the sweep
 MFMA_GEOMS = ([f"-1,1,1,{kt}" for kt in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 21)]
               + [f"-1,1,2,{kt}" for kt in range(1, 12)]          # rows cut over 2 workgroups
+              + [f"-1,1,3,{kt}" for kt in range(1, 8)] + ["-1,1,3,0"]  # ... over 3
               + [f"-1,2,8,{kt}" for kt in range(1, 12)] + ["-1,1,1,0", "-1,1,2,0", "-1,1,0,0", "-1,2,8,0"])
 
 
 @pytest.mark.parametrize("geom", MFMA_GEOMS)
 def test_mfma_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
     _, t, cs, kt = map(int, geom.split(","))
-    waves = 7 if t == 2 else (12 if cs == 2 else 6)         # matrix waves over the rows
+    waves = 7 if t == 2 else (6 * cs if cs in (2, 3) else 6)  # matrix waves over the rows
     n = min(waves * 16 * kt - 5, 2016) if kt else 300       # x 16-row tiles, ragged; kernel limit
     p, d = 53, 16 * t + 16 * t + 7    # 3 blocks + 5 steps; partial last workgroup / tile
     inp = inputs_for("identity", n, p, d, seed=21)
