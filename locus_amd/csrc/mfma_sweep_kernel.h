@@ -405,7 +405,10 @@ mfma_sweep_kernel(const MfmaSweepParams P)
         // correction first, XW's stream after the chain) was measured slower: the chain alone
         // takes 11.6k cycles per block here, and 11.6k + 9.2k of MFMA exceeds the 19.7k of the
         // other three SIMDs, while interleaved the chain's LDS and store instructions overlap
-        // with the MFMAs.
+        // with the MFMAs.  The short-dependent-path step of mfma_sweep1_kernel.h (Estrin
+        // exponential, next dot as one FMA after the division) was tried here too: parity green
+        // but 1 % slower (block 20.1k cycles) -- next to an MFMA stream the chain pays per
+        // instruction, not per dependent level, and that form has a few more of them.
         __builtin_amdgcn_s_setprio(3);
         double c_scale = 0.0, c_hinv = 0.0, c_cst = 0.0, c_s2 = 0.0;
         if (cvalid) {
