@@ -70,7 +70,14 @@ constexpr int ring1_pairs()
 {
     // X operand pairs in flight per matrix wave (must divide 4 KT); the deep tiles keep fewer so
     // that the residual (8 KT registers) and the ring fit 256 registers without spilling
-    constexpr int cap = (KT > 14 || KT <= 6) ? 6 : 12;
+#ifdef LOCUS_RING1_CAP
+    constexpr int cap = LOCUS_RING1_CAP;
+#else
+    // (KT <= 4 runs chain-bound with one workgroup per tile: a deeper ring only delays the
+    // helper's loads; KT = 5, 6 are bound by the operand fetch, where 12 pairs in flight per wave
+    // took the n = 1000 shard from 10.9 to 10.5 ms)
+    constexpr int cap = (KT > 14 || KT <= 4) ? 6 : 12;
+#endif
     int best = 1;
     for (int r = 1; r <= cap; ++r)
         if ((4 * KT) % r == 0) best = r;
