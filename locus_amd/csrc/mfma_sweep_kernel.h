@@ -127,7 +127,9 @@ constexpr int ring_pairs()
 #if defined(LOCUS_RING_T1) && defined(LOCUS_RING_T2)
     constexpr int cap = (T == 1) ? LOCUS_RING_T1 : LOCUS_RING_T2;
 #else
-    constexpr int cap = (T == 1) ? (KT > 18 ? 7 : 12) : 6;  // KT = 21: 168 residual registers
+    // KT = 21 at T = 1: 168 residual registers.  T = 2: 9 pairs while the 16 KT residual registers
+    // leave room (KT = 9, n = 1000: 8.80 -> 8.69 ms for 16 000 steps; 12 gave 8.77), else 6
+    constexpr int cap = (T == 1) ? (KT > 18 ? 7 : 12) : (KT <= 9 ? 9 : 6);
 #endif
     int best = 1;
     for (int r = 1; r <= cap; ++r)
