@@ -448,8 +448,8 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
 
 // Row-split cluster size for `tiles` tiles of 16 responses.  One workgroup per tile while its two
 // matrix waves per SIMD have less work per block than the chain (a wave issues 8 KT MFMAs of 64
-// cycles per block: KT <= 4 is <= 4096 cycles against a chain of ~5600; C2, n = 200: 3.31 ms with
-// one workgroup, 3.66 with two).  Otherwise 2 when the members of every cluster fit on the chip at
+// cycles per block: KT <= 4 is <= 4096 cycles against a chain of ~5600; n = 200, p = 20 000,
+// d = 1000: 3.31 ms with one workgroup, 3.66 with two).  Otherwise 2 when the members of every cluster fit on the chip at
 // once.  3 is instantiated and tested but not chosen: at n = 1000 the matrix waves get lighter
 // (5260 cycles per block against 7660) and the helper wave, which shares its SIMD's vector ALU
 // with the chain, becomes the limit (10.97 ms against 10.99).  LOCUS_HIP_MFMA_CS overrides (1, 2, 3).
