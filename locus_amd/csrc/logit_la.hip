@@ -78,7 +78,7 @@ constexpr int la_depth()
 {
     // r, w, xw (3 CR) and a ring of D columns, NPL doubles each, must leave ~70 of the 256
     // VGPRs to the reductions and addresses
-    return ((3 * CR + 8) * NPL <= 80) ? 8 : (((3 * CR + 4) * NPL <= 84) ? 4 : 2);
+    return ((3 * CR + 8) * NPL <= 84) ? 8 : (((3 * CR + 4) * NPL <= 84) ? 4 : 2);
 }
 
 template <int CR>
