@@ -16,9 +16,10 @@
 // vector side (~45 FMAs, one transposing wave reduction), instead of their sum.
 //
 // Geometry: workgroup = 8 waves = 7 vector waves + 1 chain wave, CR in {1, 2, 4} responses per
-// workgroup (one workgroup per CU: d_loc <= CR * CUs), lane l of vector wave v holds rows
-// (v * NPL + i) * 64 + l, i < NPL, of R, W2 and the current X o W2 in VGPRs for the whole sweep.
-// X columns are read straight from the packed matrix (coalesced 512-byte rows per wave) through a
+// workgroup (one workgroup per CU: d_loc <= CR * CUs), lane l of vector wave v holds NPL rows of
+// the wave's slice (consecutive rows in pairs: 16-byte loads) of R, W2 and the current X o W2 in
+// VGPRs for the whole sweep.
+// X columns are read straight from the packed matrix (coalesced 1 KB rows per wave) through a
 // register ring XD steps ahead; per-(j, k) state (beta_old, sig2_beta, xwx, log sig2_beta / 2)
 // through a ring of the chain wave.
 #include "sweep_kernel.h"
@@ -99,7 +100,13 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
     constexpr int NK = 2 * CR;
     constexpr int UN = kLaUnroll;
     const int n = P.n, d = P.d, ld = P.ld;
-    const int rbase = wave * NPL * 64 + lane;
+    // Row of register i of this lane: consecutive rows in pairs, so that a column is fetched with
+    // 16-byte loads (half the load instructions; the dot products do not care which lane holds
+    // which row).  An odd NPL keeps one 8-byte load for its last register.
+    auto row_of = [&](int i) {
+        return (NPL % 2 == 1 && i == NPL - 1) ? wave * NPL * 64 + (NPL - 1) * 64 + lane
+                                              : wave * NPL * 64 + (i >> 1) * 128 + 2 * lane + (i & 1);
+    };
     double r[CR][NPL], w[CR][NPL], xw[CR][NPL];
 #pragma unroll
     for (int cc = 0; cc < CR; ++cc) {
@@ -108,7 +115,7 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
         const double* Wk = P.W2 + (size_t)kk * n;
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
-            const int row = rbase + i * 64;
+            const int row = row_of(i);
             const bool ok = (kk < d) && (row < n);
             r[cc][i] = ok ? Rk[row] : 0.0;
             w[cc][i] = ok ? Wk[row] : 0.0;
@@ -122,17 +129,24 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
     // byte offsets of this lane's rows inside a packed column; rows past the column's padding
     // (the workgroup may cover more than ld rows) are clamped: r = w = 0 there, so whatever
     // finite value is read contributes nothing
-    unsigned boff[NPL];
+    unsigned boff[NPL];   // of a pair: the even register's entry (ld is even: pairs never straddle it)
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        const int row = rbase + i * 64;
-        boff[i] = 8u * (unsigned)(row < ld ? row : ld - 1);
+        const int row = row_of(i);
+        const bool paired = !(NPL % 2 == 1 && i == NPL - 1);
+        boff[i] = 8u * (unsigned)(row < ld ? row : (paired ? ld - 2 + (i & 1) : ld - 1));
     }
     auto load_col = [&](int j, double (&x)[NPL]) {
         const char* col = reinterpret_cast<const char*>(
             P.Xp + (size_t)__builtin_amdgcn_readfirstlane(j) * ld);  // uniform: scalar base
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) x[i] = *reinterpret_cast<const double*>(col + boff[i]);
+        for (int i = 0; i + 1 < NPL; i += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(col + boff[i]);
+            x[i] = v.x;
+            x[i + 1] = v.y;
+        }
+        if constexpr (NPL % 2 == 1)
+            x[NPL - 1] = *reinterpret_cast<const double*>(col + boff[NPL - 1]);
     };
     // step records through VECTOR loads (lane-uniform address): a scalar load would share
     // lgkmcnt with the LDS traffic of the step, and every LDS wait would then also wait for a
@@ -256,7 +270,7 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
         double a0 = 0.0;
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
-            const int row = rbase + i * 64;
+            const int row = row_of(i);
             if ((kk < d) && (row < n)) Rk[row] = r[cc][i];
             a0 = fma(r[cc][i], r[cc][i], a0);
         }
@@ -569,8 +583,8 @@ int run_logit_la_sweep(const SweepParams& prm, const SweepConfig& cfg, hipStream
         cr = prm.d <= cus ? 1 : (prm.d <= 2 * cus ? 2 : 4);
         if (cr > logit_la_max_cr(prm.n)) cr = logit_la_max_cr(prm.n);
     }
-    if (prm.ld < prm.n || (prm.ld & 127) != 0) {
-        set_error("logit look-ahead sweep: packed X needs ld >= n, ld % 128 == 0");
+    if (prm.ld < prm.n || (prm.ld & 127) != 0 || (reinterpret_cast<uintptr_t>(prm.Xp) & 15) != 0) {
+        set_error("logit look-ahead sweep: packed X needs ld >= n, ld % 128 == 0, 16-byte alignment");
         return LOCUS_HIP_EINVAL;
     }
     const dim3 grid((unsigned)((prm.d + cr - 1) / cr));
