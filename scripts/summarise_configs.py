@@ -29,8 +29,11 @@ for cfg in cfgs:
     n, p, d = SHAPES[cfg]
     nsweeps = max([len(v) for k, v in fetch.items() if "build_steps_kernel" in k] + [1])
     seq = [k for k in fetch if any(s in k for s in SWEEP)]
-    rd = sum(sum(fetch[k]) for k in seq) * 2 * 1024 / nsweeps
-    wr = sum(sum(write.get(k, [0])) for k in seq) * 1024 / nsweeps
+    # median dispatch of every kernel x its dispatches per sweep: the first dispatches of a
+    # process read cold (up to 6x the steady-state misses) and would dominate a mean over 4 sweeps
+    med = lambda v: sorted(v)[(len(v) - 1) // 2]  # lower median
+    rd = sum(med(fetch[k]) * len(fetch[k]) for k in seq) * 2 * 1024 / nsweeps
+    wr = sum(med(write.get(k, [0])) * len(write.get(k, [0])) for k in seq) * 1024 / nsweeps
     traffic.append(dict(config=cfg, n=n, p=p, d_loc=d, sweeps=nsweeps,
                         kernel="sweep sequence: " + "; ".join(
                             f"{k[:60]} x{len(fetch[k]) / nsweeps:g}" for k in seq),

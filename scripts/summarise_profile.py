@@ -19,25 +19,28 @@ def counter(dirname, name):
 
 fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
 lines = ["# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1",
-         "# values in KiB per dispatch as reported; hbm_read applies the gfx950 correction of",
+         "# values in KiB per dispatch as reported, median over the dispatches (the first ones read cold); hbm_read applies the gfx950 correction of",
          "# MI355X_MICROARCH.md §HBM (FETCH_SIZE reports 1/2 of wide coalesced reads) = 2 x FETCH_SIZE",
-         "kernel,calls,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_read_bytes,hbm_write_bytes"]
+         "kernel,calls,FETCH_SIZE_KiB_median,WRITE_SIZE_KiB_median,hbm_read_bytes,hbm_write_bytes"]
 traffic = []
 # one sweep = the kernels locus_hip_sweep_dev launches; build_steps_kernel runs once per sweep
 nsweeps = max([len(v) for k, v in fetch.items() if "build_steps_kernel" in k] + [1])
 SWEEP = ("sweep_kernel", "sweep1_kernel", "pack_blocks", "build_steps_kernel", "logit_la_kernel")
 seq = [k for k in fetch if any(s in k for s in SWEEP)]
 if seq:
-    rd = sum(sum(fetch[k]) for k in seq) * 2 * 1024 / nsweeps
-    wr = sum(sum(write.get(k, [0])) for k in seq) * 1024 / nsweeps
+    # median dispatch of every kernel x its dispatches per sweep: the first dispatches of a
+    # process read cold (up to 6x the steady-state misses) and would dominate a mean over 4 sweeps
+    med = lambda v: sorted(v)[(len(v) - 1) // 2]  # lower median
+    rd = sum(med(fetch[k]) * len(fetch[k]) for k in seq) * 2 * 1024 / nsweeps
+    wr = sum(med(write.get(k, [0])) * len(write.get(k, [0])) for k in seq) * 1024 / nsweeps
     traffic.append(dict(config="bench", n=n, p=p, d_loc=d_loc, kernel="sweep sequence: " + "; ".join(
                             f"{k[:60]} x{len(fetch[k]) / nsweeps:g}" for k in seq),
                         hbm_bytes_per_launch=rd + wr, hbm_read_bytes=rd, hbm_write_bytes=wr,
                         correction="2 x FETCH_SIZE (gfx950, 16-B coalesced loads) + WRITE_SIZE, "
                                    "summed over the kernels of one sweep"))
 for k in sorted(fetch, key=lambda k: -sum(fetch[k])):      # one row per kernel, largest reader first
-    fs = sum(fetch[k]) / len(fetch[k])
-    ws = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
+    fs = sorted(fetch[k])[(len(fetch[k]) - 1) // 2]                # median dispatch (see above)
+    ws = sorted(write.get(k, [0]))[(len(write.get(k, [0])) - 1) // 2]
     lines.append(f"\"{k[:80]}\",{len(fetch[k])},{fs:.1f},{ws:.1f},{2*fs*1024:.4e},{ws*1024:.4e}")
     if any(s in k for s in SWEEP[:2] + SWEEP[4:]):
         traffic.append(dict(config="bench", n=n, p=p, d_loc=d_loc, kernel=k, per="dispatch of this kernel",
