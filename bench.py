@@ -151,6 +151,11 @@ def committed_traffic(n, p, d_loc):
 
 
 def main():
+    # LOCUS_BENCH_WATCHDOG=<seconds>: dump every thread's Python stack and exit if the run is still
+    # going after that long (a rank stuck in a collective or a kernel names itself instead of hanging)
+    if os.environ.get("LOCUS_BENCH_WATCHDOG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LOCUS_BENCH_WATCHDOG"]), exit=True)
     args = parse()
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

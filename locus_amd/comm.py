@@ -37,11 +37,19 @@ class DistComm(Comm):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self._sync_first = dist.get_backend(group) == "gloo"
 
     def shard(self, d):
         return (d * self.rank) // self.world, (d * (self.rank + 1)) // self.world
 
     def all_reduce_sum_(self, t):
+        if t.is_cuda and self._sync_first:
+            # gloo stages device tensors through the host on streams of its own.  Two ranks that
+            # share one GPU (the one-GPU rehearsal of the N > 1 path, tests) stalled there with a
+            # long sweep still queued: drain this rank's stream first.  RCCL enqueues the
+            # collective on the stream and needs none of this.
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t
 
