@@ -615,6 +615,34 @@ def test_identity_two_ranks_share_the_gpu(oracle, hip):
         assert err is None, f"rank {rank}: {err}"
 
 
+def test_bench_two_ranks_share_the_gpu(hip):
+    """bench.py's N > 1 path end to end (torch.distributed.run, two ranks over gloo on ONE GPU) at a
+    size where every rank has a long sweep queued when it reaches the all-reduce: d_loc = 5000
+    responses per rank, p = 2000.  This stalled inside gloo until DistComm drained the stream
+    first; the watchdog turns a stall into a failure with stacks instead of a hang."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, LOCUS_BENCH_BACKEND="gloo", LOCUS_BENCH_WATCHDOG="90")
+    env.pop("LOCUS_HIP_SWEEP_CFG", None)
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+         "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--p", "2000"],
+        cwd=root, env=env, capture_output=True, text=True, timeout=200)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["d_per_gpu"] == 5000
+    assert rec["config"]["elbo_monotone"]
+
+
 @pytest.mark.parametrize("batch", ["x-y", "x", "0"])
 def test_identity_internal_batch_schemes(oracle, hip, batch):
     """The reference's internal schemes of locus_core_ (R/locus_core.R:97-161; "convergence not
