@@ -130,6 +130,48 @@ def test_mfma_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
     assert_parity(got, ref, what=f"identity mfma geom {geom}")
 
 
+EXTREME_CFGS = [("identity", "0,0,0,0"), ("identity", "-1,2,8,0"), ("identity", "-1,1,1,0"),
+                ("identity", "-1,1,2,0"), ("identity", "-1,1,3,0"), ("identity", "4,1,1,1"),
+                ("logit", "0,0,0,0"), ("logit", "-3,2,0,0"), ("logit", "4,1,1,1")]
+
+
+@pytest.mark.parametrize("variant,geom", EXTREME_CFGS)
+def test_extreme_log_odds(oracle, hip, variant, geom, monkeypatch):
+    """Prior log-odds far outside the range of exp: gam must saturate at 0 / 1 exactly as the
+    reference's logOnePlusExp does (src/utils.cpp:3-12), through every kernel's own sigmoid
+    (Horner and Estrin exponentials, clamp at -800, Newton division)."""
+    n, p, d = 300, 53, 39
+    inp = inputs_for(variant, n, p, d, seed=77)
+    inp["log_om_vb"][[3, 17]] = [-2000.0, -745.5]          # gam -> 0
+    inp["log_1_min_om_vb"][[5, 40]] = [-1.0e4, -700.0]     # gam -> 1
+    inp["log_om_vb"][8], inp["log_1_min_om_vb"][8] = -1.0e-300, -690.0
+    ref = call_variant(oracle, variant, inp)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", geom)
+    got = call_variant(hip, variant, inp)
+    assert_parity(got, ref, what=f"{variant} {geom} extreme log-odds")
+    g = got["gam_vb"]
+    assert (g[3] < 1e-300).all() and (g[5] == 1.0).all() and np.isfinite(g).all()
+
+
+@pytest.mark.parametrize("variant,geom", [c for c in EXTREME_CFGS if c[1] != "4,1,1,1"])
+def test_nan_log_odds_propagate(oracle, hip, variant, geom, monkeypatch):
+    """A NaN prior log-odds of one covariate: the reference's std::exp propagates it into gam, beta
+    and, through the residual, into everything visited later.  The kernels clamp their exponent
+    with a select (not fmax), so the same entries are NaN -- none is silently turned into 0 or 1."""
+    n, p, d = 200, 40, 21
+    inp = inputs_for(variant, n, p, d, seed=5)
+    j = int(inp["shuffled_ind"][25])        # visited 26th: 25 clean updates before it
+    inp["log_om_vb"][j] = np.nan
+    ref = call_variant(oracle, variant, inp)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", geom)
+    got = call_variant(hip, variant, inp)
+    for k in ref:
+        assert np.array_equal(np.isnan(np.asarray(got[k])), np.isnan(np.asarray(ref[k]))), f"{k}: NaN pattern differs"
+        ok = ~np.isnan(np.asarray(ref[k]))
+        np.testing.assert_allclose(np.asarray(got[k])[ok], np.asarray(ref[k])[ok], rtol=1e-9, atol=1e-11)
+    assert np.isnan(ref["gam_vb"][j]).all() and not np.isnan(ref["gam_vb"]).all()
+
+
 @pytest.mark.parametrize("variant", ["identity", "z", "struct", "probit"])
 @pytest.mark.parametrize("shape", [(200, 500, 20), (1000, 64, 41), (100, 16, 3), (64, 7, 1),
                                    (333, 1, 5), (500, 33, 70)])
