@@ -449,10 +449,11 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
 // Row-split cluster size for `tiles` tiles of 16 responses.  One workgroup per tile while its two
 // matrix waves per SIMD have less work per block than the chain (a wave issues 8 KT MFMAs of 64
 // cycles per block: KT <= 4 is <= 4096 cycles against a chain of ~5600; n = 200, p = 20 000,
-// d = 1000: 3.31 ms with one workgroup, 3.66 with two).  Otherwise 2 when the members of every cluster fit on the chip at
-// once.  3 is instantiated and tested but not chosen: at n = 1000 the matrix waves get lighter
-// (5260 cycles per block against 7660) and the helper wave, which shares its SIMD's vector ALU
-// with the chain, becomes the limit (10.97 ms against 10.99).  LOCUS_HIP_MFMA_CS overrides (1, 2, 3).
+// d = 1000: 3.31 ms with one workgroup, 3.66 with two).  Otherwise the rows are cut over 2 or 3
+// workgroups when the members of every cluster fit on the chip at once: 3 when a 2-cluster's
+// matrix waves would still be bound by their operand fetch (KT >= 5 at CS = 2, n > 768:
+// n = 1000, d_loc = 1250: 10.0 ms against 10.5; C2 4.04 against 4.20), 2 below that (n = 500,
+// d = 1000: 3.88 ms against 3.95).  LOCUS_HIP_MFMA_CS overrides (1, 2, 3).
 static int choose_cs(int n, int tiles)
 {
     int want = 0;
@@ -464,8 +465,9 @@ static int choose_cs(int n, int tiles)
         const bool ok = mfma1_kt_for(n, want) > 0 && cus >= 8 * want;
         return ok ? want : 1;
     }
-    const int kt1 = mfma1_kt_for(n, 1), kt2 = mfma1_kt_for(n, 2);
+    const int kt1 = mfma1_kt_for(n, 1), kt2 = mfma1_kt_for(n, 2), kt3 = mfma1_kt_for(n, 3);
     if (kt1 > 0 && kt1 <= 4) return 1;
+    if (kt3 > 0 && kt2 >= 5 && t8 * 3 <= cus) return 3;
     return (kt2 > 0 && t8 * 2 <= cus) ? 2 : 1;
 }
 

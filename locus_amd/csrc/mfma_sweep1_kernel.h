@@ -624,6 +624,13 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         __syncthreads();  // E2
     } else {
         // =========================== helper role ==========================================
+        // This wave shares SIMD 3 with the chain wave, whose ~72 VALU instructions per step keep the
+        // vector ALU 80 % busy; the older wave wins the issue arbitration, so the helper's ~300
+        // VALU instructions per block crawled behind it (7900 cycles per block at CS = 3, where
+        // the helper is the last to reach the barrier).  With three members it goes first:
+        // 10.9 -> 10.0 ms at n = 1000, d_loc = 1250.  CS = 1, 2 are bound elsewhere and lose
+        // when the chain is delayed (n = 200, CS = 1: 3.31 -> 3.6 ms), so they keep the default.
+        if constexpr (CS == 3) __builtin_amdgcn_s_setprio(2);
         const int kh = k0 + r;
         const bool kvalid = kh < kend;
         const bool storer = (c_mem == 0);
