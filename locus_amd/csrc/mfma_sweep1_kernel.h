@@ -627,8 +627,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         // This wave shares SIMD 3 with the chain wave, whose ~72 VALU instructions per step keep the
         // vector ALU 80 % busy; the older wave wins the issue arbitration, so the helper's ~300
         // VALU instructions per block crawled behind it (7900 cycles per block at CS = 3, where
-        // the helper is the last to reach the barrier).  With three members it goes first:
-        // 10.9 -> 10.0 ms at n = 1000, d_loc = 1250.  CS = 1, 2 are bound elsewhere and lose
+        // the helper is the last to reach the barrier).  With three members it goes first from
+        // the barrier until its requests are issued (reduced G, flags, loads), then steps back:
+        // 10.9 -> 9.84 ms at n = 1000, d_loc = 1250.  CS = 1, 2 are bound elsewhere and lose
         // when the chain is delayed (n = 200, CS = 1: 3.31 -> 3.6 ms), so they keep the default.
         if constexpr (CS == 3) __builtin_amdgcn_s_setprio(2);
         const int kh = k0 + r;
@@ -652,6 +653,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 
         for (int it = 0; it < nit; ++it) {
             __syncthreads();  // B1
+            if constexpr (CS == 3) __builtin_amdgcn_s_setprio(2);  // see the top of this role
             M1STAMP(0);
             const int bn_blk = it - L + 2;   // block the chain runs in the next iteration
             const int bs = it - L;           // block the chain finished in the last iteration
@@ -777,6 +779,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     }
                 }
             }
+            // everything the chain and the memory system wait for is out: back behind the chain
+            // (hand-over and result stores have until the barrier; 10.08 -> 9.84 ms)
+            if constexpr (CS == 3) __builtin_amdgcn_s_setprio(0);
             M1STAMP(4);
             // ---- hand over what was requested: the ONE wait for global memory of this iteration.
             // Every store of the iteration comes after it (the memory counter is in order: a wait
