@@ -153,8 +153,8 @@ typedef struct locus_hip_sweep_args {
                                    NPL = -1: matrix-core kernel (identity family) with C = tiles
                                    of 16 responses per workgroup (1, 2; 0 = planned from d);
                                    C = 1: S = workgroups sharing the rows of a tile (1, 2, 3;
-                                   0 = 1 for n <= 384, else 2 when the tiles fit twice on the
-                                   CUs); G = 16-row tiles
+                                   0 = 1 for n <= 384, else 3 (n > 768) or 2 when that many
+                                   workgroups per tile fit on the CUs); G = 16-row tiles
                                    per matrix wave (0 = smallest that fits n);
                                    NPL = -2: streaming kernel (any n; what "automatic" picks
                                    above 4096 rows), C, S, G ignored;
