@@ -184,6 +184,20 @@ def test_mfma_sweep_variants(oracle, hip, variant, shape, monkeypatch):
     assert_parity(got, ref, what=f"{variant} {shape} mfma")
 
 
+@pytest.mark.parametrize("n,d", [(769, 1270), (1000, 1280), (1000, 1281), (1153, 700), (2016, 1000),
+                                 (384, 900), (385, 900), (768, 1300), (1000, 4100)])
+def test_default_dispatch_cluster_boundaries(oracle, hip, n, d, monkeypatch):
+    """Default dispatch around the limits of the cluster-size choice (one workgroup per tile up
+    to n = 384; three per tile for n > 768 while 3 x tiles fit on the CUs, else two, else one)
+    and of the instantiated row tilings, with ragged last tiles; d = 4100 adds the planned split
+    into a T = 2 launch and a clustered remainder.  Short sweep (p = 40) against the oracle."""
+    monkeypatch.delenv("LOCUS_HIP_SWEEP_CFG", raising=False)
+    inp = inputs_for("identity", n, 40, d, seed=n + d)
+    ref = call_variant(oracle, "identity", inp)
+    got = call_variant(hip, "identity", inp)
+    assert_parity(got, ref, what=f"identity default dispatch n={n} d={d}")
+
+
 @pytest.mark.parametrize("variant", ["identity", "struct"])
 def test_mfma_planned_multi_launch(oracle, hip, variant, monkeypatch):
     """The default (planned) mode splits the responses over several launches when they exceed
