@@ -8,26 +8,30 @@
 // re-cut so that the sequential element-wise chain carries nothing but the chain:
 //
 //   waves 0,1,2,4,5,6 (matrix role, SIMDs 0..2): rows of the residual tile as MFMA accumulators,
-//       X operands streamed from global memory in consumption order; matrix wave 0 also forms the
-//       cross-block corrections of the block the chain runs NEXT (lags L-1..2 from deltas that are
-//       known, lag 1 by following the chain's progress word) on top of the reduced G and leaves
-//       the chain its starting values gx[t][response];
-//   wave 3 (chain role, alone with the helper on SIMD 3): per step ONE LDS read of gx, ONE of
-//       beta_old, the step's scalars and Gram column through the scalar cache (s_load: they are
-//       wave-uniform), the update, three LDS writes (delta, mu, gamma).  No global memory access,
-//       no partial-sum tree, no address arithmetic;
-//   wave 7 (helper role): everything else, off the critical path -- sums the matrix waves' partial
-//       G tiles, exchanges them with the other workgroups of the cluster, stages beta_old, writes
-//       gam / mu / beta of the block the chain finished one iteration ago to global memory and
-//       accumulates the fused column statistics.
+//       X operands streamed from global memory in consumption order.  Matrix waves 1 .. L-2 also
+//       form the cross-block corrections of the known lags (l >= 2) of the block the chain runs
+//       next; with one workgroup per tile matrix wave 0 adds them to the reduced G and follows
+//       the chain's progress word for lag 1;
+//   wave 3 (chain role, with the helper on SIMD 3, which runs no MFMA stream): per step ONE LDS
+//       read of gx, ONE of beta_old, the step's scalars and Gram column as LDS broadcasts, the
+//       update (26 dependent instructions, everything else in their latency gaps), three LDS
+//       writes (delta, mu, gamma).  No global memory access, no partial-sum tree, no address
+//       arithmetic.  In a cluster it also finishes gx of its next block right after its 16th
+//       step (lag 1: four MFMAs on the deltas it just wrote);
+//   wave 7 (helper role): everything else -- sums the matrix waves' partial G tiles, exchanges
+//       them with the other workgroups of the cluster, stages beta_old, scalars, Gram columns
+//       and cross-Gram operands one block ahead, writes gam / mu / beta of the block the chain
+//       finished one iteration ago to global memory and accumulates the fused column statistics.
 //
-// Row-split clusters (CS > 1): the 16 responses' rows are cut over CS workgroups on CS CUs.  Each
-// member projects / updates its own rows, publishes its partial G tile (2 KB per block) through
-// global memory (agent-scope stores + a monotone flag, MI355X_MICROARCH.md "Valid forms", row 1),
-// and EVERY member runs the same chain on the same sums (added in member order, so the chains are
-// bit-identical and no delta ever has to travel).  The look-ahead is deepened to L = 5 blocks so
-// that a partial tile has two block times (~7 us) to arrive.  All waits are bounded: a partner that
-// does not show up raises the error word instead of hanging the GPU.
+// Row-split clusters (CS = 2, 3): the 16 responses' rows are cut over CS workgroups on CS CUs.
+// Each member projects / updates its own rows, publishes its partial G tile (2 KB per block)
+// through global memory as tagged 8-byte granules {32 bits of a double, block + 1} written and
+// read with agent-scope relaxed atomics (a granule is valid when its tag matches: no flag, no
+// fence in steady state), and EVERY member runs the same chain on the same sums (added in member
+// order, so the chains are bit-identical and no delta ever has to travel).  The look-ahead is
+// deepened to L = 5 blocks so that a partial tile has two block times (~6 us) to arrive.  All
+// waits are bounded: a partner that does not show up raises the error word instead of hanging
+// the GPU.
 #pragma once
 #include "mfma_sweep_kernel.h"
 
