@@ -198,6 +198,19 @@ def test_default_dispatch_cluster_boundaries(oracle, hip, n, d, monkeypatch):
     assert_parity(got, ref, what=f"identity default dispatch n={n} d={d}")
 
 
+@pytest.mark.parametrize("variant", ["identity", "z", "struct", "probit"])
+@pytest.mark.parametrize("shape", [(1000, 64, 41), (500, 33, 70), (130, 21, 3)])
+def test_mfma_three_member_clusters_variants(oracle, hip, variant, shape, monkeypatch):
+    """Rows cut over three workgroups (the default for n > 768 and <= 80 tiles) for every member of
+    the identity family, ragged rows and tiles included."""
+    n, p, d = shape
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", "-1,1,3,0")
+    inp = inputs_for(variant, n, p, d, seed=3 * n + p + d, c=0.6 if variant == "identity" else 1.0)
+    ref = call_variant(oracle, variant, inp)
+    got = call_variant(hip, variant, inp)
+    assert_parity(got, ref, what=f"{variant} {shape} three-member clusters")
+
+
 @pytest.mark.parametrize("variant", ["identity", "struct"])
 def test_mfma_planned_multi_launch(oracle, hip, variant, monkeypatch):
     """The default (planned) mode splits the responses over several launches when they exceed
