@@ -48,7 +48,9 @@ for k in sorted(fetch, key=lambda k: -sum(fetch[k])):      # one row per kernel,
                             fetch_size_kib=fs, write_size_kib=ws,
                             correction="2 x FETCH_SIZE (gfx950, 16-B coalesced loads) + WRITE_SIZE"))
 open(f"profiles/{tag}_bench_hbm_counters.csv", "w").write("\n".join(lines) + "\n")
-json.dump(traffic, open(f"profiles/traffic_{tag}.json", "w"), indent=1)
+tpath = f"profiles/traffic_{tag}.json"   # the per-config records of summarise_configs.py stay
+keep = [t for t in (json.load(open(tpath)) if os.path.exists(tpath) else []) if t.get("config") != "bench"]
+json.dump(traffic + keep, open(tpath, "w"), indent=1)
 print("\n".join(lines[:12]))
 print(traffic)
 
