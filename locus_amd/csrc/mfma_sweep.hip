@@ -162,8 +162,9 @@ pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ st
                    double* __restrict__ sc4, int* __restrict__ jidx, int ld, int KT, int nblk, int MW,
                    int d)
 {
-    __shared__ double xt[16][130];
-    __shared__ double xn[16][130];
+    __shared__ double pk_lds[2 * 16 * 130];   // the two X tiles; reused for the Gram reduction
+    double (*xt)[130] = reinterpret_cast<double (*)[130]>(pk_lds);
+    double (*xn)[130] = reinterpret_cast<double (*)[130]>(pk_lds + 16 * 130);
     __shared__ int js[16], jn[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nit = nblk + 2;
@@ -181,7 +182,13 @@ pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ st
     const int rows_pad = MW * 16 * KT;
     const int NOP = 8 * KT;
     const int gt = tid >> 4, gs = tid & 15;
-    double gacc = 0.0, xacc = 0.0;
+    // Gram tiles X_b' X_b and X_{b+1}' X_b on the matrix cores, as in pack_blocks1_kernel: wave w
+    // contracts rows 32 w .. 32 w + 31 of every 128-row chunk, the four partial tiles are added
+    // through LDS at the end (0.49 -> 0.47 ms at p = 50 000: the kernel is bound by its 8-byte
+    // operand stores, two interleaved streams per 16-byte slot, not by this)
+    typedef double pk_d4 __attribute__((ext_vector_type(4)));
+    const int wv4 = tid >> 6, ln4 = tid & 63;
+    pk_d4 m0 = (pk_d4){0.0, 0.0, 0.0, 0.0}, m1 = m0;
     for (int c0 = 0; c0 < rows_pad; c0 += 128) {
         __syncthreads();
 #pragma unroll
@@ -218,10 +225,31 @@ pack_blocks_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ st
                 }
             }
         }
-        for (int rr = 0; rr < 128; ++rr) {
-            gacc = fma(xt[gt][rr], xt[gs][rr], gacc);
-            xacc = fma(xn[gt][rr], xt[gs][rr], xacc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            // A[i = t][k = row] and B[k = row][j = s] are both read as
+            // [column = lane & 15][row = 4 (8 w + q) + (lane >> 4)]
+            const int rr = 4 * (8 * wv4 + q) + (ln4 >> 4);
+            const double a = xt[ln4 & 15][rr], an = xn[ln4 & 15][rr];
+            m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, m0, 0, 0, 0);    // X_b' X_b
+            m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(an, a, m1, 0, 0, 0);   // X_{b+1}' X_b
         }
+    }
+    // D[t = (lane >> 4) + 4 r][s = lane & 15]: partial tiles of the four waves -> LDS -> one
+    // (t, s) pair per thread
+    __syncthreads();
+    double* red = pk_lds;  // [wave][product][r][lane], 2048 doubles (the X tiles are dead)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[((wv4 * 2 + 0) * 4 + r) * 64 + ln4] = m0[r];
+        red[((wv4 * 2 + 1) * 4 + r) * 64 + ln4] = m1[r];
+    }
+    __syncthreads();
+    double gacc = 0.0, xacc = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        gacc += red[((w * 2 + 0) * 4 + (gt >> 2)) * 64 + (gt & 3) * 16 + gs];
+        xacc += red[((w * 2 + 1) * 4 + (gt >> 2)) * 64 + (gt & 3) * 16 + gs];
     }
     // column gs of the strictly lower triangle: cg[b][t = gs][t' = gt]
     cg[(size_t)b * 256 + gs * 16 + gt] = (gt > gs) ? gacc : 0.0;
