@@ -33,6 +33,19 @@ extern "C" {
 #define LOCUS_HIP_EINVAL (-1)       /* bad argument (shape, null pointer, ...)   */
 #define LOCUS_HIP_EUNSUPPORTED (-2) /* shape outside what the kernels cover      */
 #define LOCUS_HIP_EPERM (-3)        /* shuffled_ind is not a permutation of 0..p-1 */
+#define LOCUS_HIP_ETIMEOUT (-4)     /* a sweep whose workgroups cooperate in clusters (rows of a
+                                       response tile cut over 2-3 CUs) gave up waiting for a
+                                       partner workgroup: the cluster was not resident at once
+                                       (another process or a CU mask held CUs, or two such sweeps
+                                       overlapped on one GPU).  The sweep stopped part-way:
+                                       gam_vb / mu_beta_vb / beta_vb rows of the covariates
+                                       visited so far hold new values, the residual and the
+                                       statistics are those from before the sweep.  Device-
+                                       resident callers re-initialise the residual from the state
+                                       (mat_x_m1 = X beta_vb) or restart; the stateless entry
+                                       points of section 1 return without touching the caller's
+                                       buffers.  The reference's sweep cannot fail half-way
+                                       (src/coreLoop.cpp:36-52).  Serialise cluster sweeps per GPU. */
 
 const char* locus_hip_last_error(void);
 int locus_hip_version(void);      /* 100 * major + minor */
@@ -171,9 +184,11 @@ typedef struct locus_hip_sweep_args {
  * makes the sweep a no-op and is reported by locus_hip_sweep_status_dev(). */
 int locus_hip_sweep_dev(const locus_hip_sweep_args* args, int logit, void* stream);
 
-/* Synchronises `stream` and returns 0, or LOCUS_HIP_EPERM if the last sweep that used
- * `workspace` (sized for p covariates) was given an invalid shuffled_ind.  workspace == NULL:
- * the static workspace of the current device (the last locus_hip_sweep_static_dev there). */
+/* Synchronises `stream` and returns 0, LOCUS_HIP_EPERM if the last sweep that used
+ * `workspace` (sized for p covariates) was given an invalid shuffled_ind (that sweep was a
+ * no-op), or LOCUS_HIP_ETIMEOUT if one of its row-split clusters timed out (state as described
+ * at LOCUS_HIP_ETIMEOUT).  workspace == NULL: the static workspace of the current device (the
+ * last locus_hip_sweep_static_dev there). */
 int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream);
 
 /* locus_hip_sweep_dev for callers that cannot allocate and have no workspace to lend: code under

@@ -17,6 +17,7 @@ class Comm:
     """Single-process stand-in: world of one, all-reduce is the identity."""
     rank = 0
     world = 1
+    solo = True      # nothing to exchange: the drivers skip the staging buffer and the collectives
 
     def shard(self, d):
         return 0, d
@@ -31,12 +32,15 @@ class Comm:
 class DistComm(Comm):
     """torch.distributed-backed communicator (backend nccl == RCCL on ROCm, or gloo)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force_collectives=False):
+        """`force_collectives`: a group of ONE rank still goes through the packed all-reduce and
+        the all-gather (a one-GPU box can then execute the RCCL branches the N > 1 runs use)."""
         import torch.distributed as dist
         self._dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.solo = self.world == 1 and not force_collectives
         self._sync_first = dist.get_backend(group) == "gloo"
 
     def shard(self, d):

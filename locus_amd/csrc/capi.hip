@@ -78,6 +78,29 @@ int check_permutation(const double* ind, int64_t p)
     return 0;
 }
 
+// The device error word of a sweep (WsView::err): bits 0, 1 from the prologue's permutation
+// check (the sweep kernels then return at entry: state untouched), bit 2 (value 4) from a
+// row-split cluster whose partner did not show up (mfma_sweep1_kernel.h: state partly written).
+int decode_sweep_error(int herr)
+{
+    if (herr & 3) {
+        set_error(herr & 1 ? "shuffled_ind: index out of range [0, p)"
+                           : "shuffled_ind: repeated index (must be a permutation of 0..p-1)");
+        return LOCUS_HIP_EPERM;
+    }
+    if (herr & 4) {
+        set_error("sweep: a row-split cluster timed out waiting for a partner workgroup (its "
+                  "workgroups were not resident at once); the sweep stopped part-way: state "
+                  "invalid, re-initialise the residual from gam_vb / mu_beta_vb");
+        return LOCUS_HIP_ETIMEOUT;
+    }
+    if (herr != 0) {
+        set_error("sweep: unknown device error word " + std::to_string(herr));
+        return LOCUS_HIP_EINVAL;
+    }
+    return 0;
+}
+
 // step records: p rounded up to a multiple of 48 (every prefetch depth of the vector kernel,
 // whole blocks of 16 for the matrix-core kernel) plus a readable tail
 size_t step_slots(int64_t p) { return ((size_t)p + 47) / 48 * 48 + 32; }
@@ -339,6 +362,9 @@ int run_loop(int kind, const double* X, const double* Y, double* gam, const doub
     a.R = dR.d(); a.state = dstate.d(); a.stats = nullptr;
     a.workspace = dws.p; a.workspace_bytes = (int64_t)workspace_bytes(n, p); a.nsteps = p;
     if ((rc = sweep_dev(&a, kind == 2, st))) return rc;
+    // the permutation was checked on the host; what can still be raised is a cluster time-out:
+    // return before anything is copied back, the caller's matrices keep their values
+    if ((rc = locus_hip_sweep_status_dev(dws.p, p, st))) return rc;
 
     // back to the reference's layout: mat_x_m1 from the residual, planes transposed back
     if ((rc = residual_transform(dY.d(), dR.d(), Zmu ? dZ.d() : nullptr,
@@ -608,12 +634,7 @@ int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream)
     LOCUS_HIP_CHECK(hipMemcpyAsync(&herr, ws.err, sizeof(int), hipMemcpyDeviceToHost,
                                    (hipStream_t)stream));
     LOCUS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    if (herr != 0) {
-        set_error(herr & 1 ? "shuffled_ind: index out of range [0, p)"
-                           : "shuffled_ind: repeated index (must be a permutation of 0..p-1)");
-        return LOCUS_HIP_EPERM;
-    }
-    return 0;
+    return decode_sweep_error(herr);
 }
 
 int locus_hip_sweep_config(int64_t n, int64_t d, int logit, int32_t* cfg)

@@ -86,6 +86,7 @@ struct SweepConfig {
 // smallest instantiated value that covers n).
 int choose_sweep_config(int n, int d, bool logit, SweepConfig* cfg);
 int device_cus();  // CUs of the current device (LOCUS_HIP_MFMA_CUS overrides: tests)
+int real_cus();    // CUs of the current device as the runtime reports them
 size_t mfma_workspace_bytes(int64_t n, int64_t p);
 bool mfma_sweep_covers(int n);
 int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,

@@ -1,5 +1,6 @@
 // Host side of the matrix-core sweep: per-sweep block packing of X and launch dispatch.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "common.h"
@@ -318,6 +319,23 @@ size_t mfma_lds_bytes(int T)
     return sizeof(double) * (2 * (size_t)(mfma_waves(T) + 1) * T * 256 + 2 * 16 * 64 + 2 * 16 * 64 + 2 * 256 + 2 * 64 + 8);
 }
 
+// CUs of the current device as the runtime reports them (cached per device)
+int real_cus()
+{
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> cache[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    int cus = cache[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+        cache[dev].store(cus, std::memory_order_relaxed);
+    }
+    return cus;
+}
+
 int device_cus()
 {
     // LOCUS_HIP_MFMA_CUS overrides the CU count the launch plan assumes (tests: forces the
@@ -326,16 +344,13 @@ int device_cus()
         const int v = atoi(e);
         if (v > 0) return v;
     }
-    static int cus = 0;  // same for every device of a node
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
+    return real_cus();
 }
+
+// CUs a row-split cluster launch may count on: the members of a cluster wait for each other, so
+// all of them must be resident at once -- never more than the device really has, whatever the
+// override says.
+static int cluster_cus() { return std::min(device_cus(), real_cus()); }
 
 // true when the matrix-core sweep covers n rows (identity family only)
 bool mfma_sweep_covers(int n) { return mfma_kt_for(n, 1) > 0; }
@@ -403,7 +418,7 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
         set_error("mfma sweep: geometry does not cover n rows");
         return LOCUS_HIP_EINVAL;
     }
-    const int cus = device_cus();
+    const int cus = (CS > 1) ? cluster_cus() : device_cus();
     const int nblk = (prm.nsteps + 15) / 16;
     const size_t nit = (size_t)nblk + L;
     const size_t xs = nit * rows_pad * 32;
@@ -428,13 +443,10 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
             hipLaunchKernelGGL(pack_blocks1_kernel<3>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
                                prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps);
         } else {
-            static bool attr_set = false;  // 83 KB of dynamic LDS: above the 64 KB default limit
-            if (!attr_set) {
-                LOCUS_HIP_CHECK(hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(pack_blocks1_kernel<5>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
-            }
+            // 83 KB of dynamic LDS: above the 64 KB default limit.  The attribute belongs to the
+            // (function, device) pair, so it is set before every launch (cheap; as in gemm.hip).
+            LOCUS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pack_blocks1_kernel<5>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(pack_blocks1_kernel<5>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
                                prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps);
         }
@@ -449,6 +461,8 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
     mp.cfac = prm.cfac;
     mp.R = prm.R; mp.state = prm.state; mp.st = prm.st;
     mp.xbuf = xbuf; mp.xflag = xflag;
+    mp.drop_member = -1;
+    if (const char* e = getenv("LOCUS_HIP_TEST_DROP_MEMBER")) mp.drop_member = atoi(e);
 
     // clusters resident at once: one workgroup per CU, members of a cluster 8 blocks apart
     const int max_tiles = std::max(1, cus / (8 * CS)) * 8;
@@ -487,7 +501,7 @@ static int choose_cs(int n, int tiles)
     int want = 0;
     if (const char* e = getenv("LOCUS_HIP_MFMA_CS")) want = atoi(e);
     if (want == 1) return 1;
-    const int cus = device_cus();
+    const int cus = cluster_cus();
     const int t8 = ((tiles + 7) / 8) * 8;
     if (want == 2 || want == 3) {
         const bool ok = mfma1_kt_for(n, want) > 0 && cus >= 8 * want;

@@ -42,7 +42,9 @@ struct Mfma1Params {
     int k_begin, k_end;   // responses [k_begin, k_end) are swept by this launch
     int ntiles;           // tiles of 16 responses = clusters
     int nblk, nsteps;     // blocks of 16 steps, active steps
-    int* err;             // bit 0/1: bad permutation (prologue); bit 2: cluster partner timed out
+    int* err;             // bits 0, 1: bad permutation (prologue); bit 2 (value 4): a cluster
+                          // partner timed out -- the members stop at the next block, store
+                          // nothing from then on and leave R as it was before the sweep
     const double* XS;     // [CS * 6][nit][8 KT][64] operand streams (pack_blocks_kernel), nit = nblk + L
     const double* cg;     // [nit][16][16]  cg[b][t][t2] = X_t2' X_t of block b for t2 > t, else 0
     const double* ax;     // [L - 1][nit + 1][64][4]  A operands of (X_b' X_{b-l}), l = 1 .. L-1
@@ -62,6 +64,8 @@ struct Mfma1Params {
     // the members' sums of squares of the residual at the end of the sweep
     unsigned long long* xbuf;
     int* xflag;           // CS > 1: [ntiles][CS][32] end-of-sweep flags of the members
+    int drop_member;      // test hook (LOCUS_HIP_TEST_DROP_MEMBER): this member of every cluster
+                          // returns at entry, as a workgroup that was never dispatched; -1 = none
 };
 
 constexpr int kXRing = 16;  // exchange slots per member; >= 2 L + 1 blocks can be in flight
@@ -150,6 +154,10 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     __shared__ int jl[8 * 16];  // covariate of the steps of the blocks around the chain [blk & 7][t]
     __shared__ int prog;        // steps the chain has completed
     __shared__ int gfin_ready;  // iteration whose gfin is complete
+    // CS > 1: 0, or the iteration at whose top every wave leaves the sweep (a partner timed out).
+    // Written by the helper during iteration it as it + 2 and read by every wave behind the
+    // barriers of it + 1 and it + 2: all waves see it at the same iteration.
+    __shared__ int dead;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -164,6 +172,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     const int g_cl = (bi / (8 * CS)) * 8 + (bi & 7);
     const int c_mem = (bi >> 3) % CS;
     if (g_cl >= P.ntiles || *P.err != 0) return;
+    if (CS > 1 && c_mem == P.drop_member) return;
     const int k0 = P.k_begin + 16 * g_cl;
     const int kend = P.k_end;
     const size_t pd = (size_t)P.p * d;
@@ -174,7 +183,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     for (int e = tid; e < 512; e += 512) gram[e] = 0.0;
     if (tid < 64) scl[tid] = 0.0;
     if (tid < 128) jl[tid] = 0;
-    if (tid == 0) { prog = 0; gfin_ready = -1; }
+    if (tid == 0) { prog = 0; gfin_ready = -1; dead = 0; }
     if (tid < 4) cxf[tid] = -1;
     __syncthreads();
 #ifdef LOCUS_STAMPS
@@ -213,6 +222,10 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         for (int it = 0; it < nit; ++it) {
             const int par = it & 1;
             __syncthreads();  // B1
+            if constexpr (CS > 1) {
+                const int dd_ = lds_peek(&dead);
+                if (dd_ != 0 && it >= dd_) break;
+            }
             M1STAMP(0);
             double bop[4];
             {
@@ -362,6 +375,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #endif
 
         __syncthreads();  // E1: everybody is done with `part`
+        const bool alive = (CS == 1) || lds_peek(&dead) == 0;
         int lane_e = lane, n_e = n, d_e = kend;
         asm volatile("" : "+v"(lane_e));
         asm volatile("" : "+s"(n_e), "+s"(d_e));
@@ -376,7 +390,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 for (int g = 0; g < 4; ++g) {
                     const int row = row0 + 16 * i + 4 * g + q_e;
                     const double v = rv[i][g];
-                    if (k < d_e && row < n_e) Rk[row] = v;
+                    if (alive && k < d_e && row < n_e) Rk[row] = v;
                     a0 = fma(v, v, a0);
                 }
             part[m * 64 + lane] = a0;
@@ -396,6 +410,10 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 
         for (int it = 0; it < nit; ++it) {
             __syncthreads();  // B1
+            if constexpr (CS > 1) {
+                const int dd_ = lds_peek(&dead);
+                if (dd_ != 0 && it >= dd_) break;
+            }
             M1STAMP(0);
             const int b = it - L + 1;  // block whose chain runs now
             if (b >= 0 && b < P.nblk && lane < 16) {
@@ -657,6 +675,10 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 
         for (int it = 0; it < nit; ++it) {
             __syncthreads();  // B1
+            if constexpr (CS > 1) {
+                const int dd_ = lds_peek(&dead);
+                if (dd_ != 0 && it >= dd_) break;
+            }
             if constexpr (CS == 3) __builtin_amdgcn_s_setprio(2);  // see the top of this role
             M1STAMP(0);
             const int bn_blk = it - L + 2;   // block the chain runs in the next iteration
@@ -694,6 +716,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                         for (int spin = 0;; ++spin) {
                             if (spin > (1 << 19)) {  // ~0.5 s: the partner is not running
                                 if (lane == 0) atomicOr(P.err, 4);
+                                if (lds_peek(&dead) == 0) lds_publish(&dead, it + 2);
                                 break;
                             }
                             __builtin_amdgcn_s_sleep(4);
@@ -833,7 +856,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 }
             }
             // ---- results of the block the chain finished last iteration -----------------------
-            if (storer && bs >= 0 && bs < P.nblk && kvalid) {
+            if (storer && bs >= 0 && bs < P.nblk && kvalid && (CS == 1 || lds_peek(&dead) == 0)) {
                 const double* mp = mg + (bs & 1) * 512 + q * 16 + r;
                 const int* jp = jl + (bs & 7) * 16 + q;
 #pragma unroll
@@ -856,6 +879,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         }
         M1STAMP_FLUSH(3);
         __syncthreads();  // E1
+        const bool alive = (CS == 1) || lds_peek(&dead) == 0;
         // column statistics: sum the four step classes of a response through LDS (gfin is free)
         gfin[lane] = acc_g;
         gfin[64 + lane] = acc_m2;
@@ -869,7 +893,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 rss += (pp[0] + pp[16]) + (pp[32] + pp[48]);
             }
         }
-        if constexpr (CS > 1) {
+        if (CS > 1 && alive) {
             // sum of squares over the members' row slices, added in member order by member 0
             double* rs_base = reinterpret_cast<double*>(xb_tile + (size_t)kXRing * CS * 512);
             if (lane < 16)
@@ -897,7 +921,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 }
             }
         }
-        if (P.st != nullptr && storer && lane < 16 && kvalid) {
+        if (alive && P.st != nullptr && storer && lane < 16 && kvalid) {
             const double* sp = gfin + lane;
             P.st[kh] = (sp[0] + sp[16]) + (sp[32] + sp[48]);
             P.st[(size_t)d + kh] = (sp[64] + sp[80]) + (sp[96] + sp[112]);

@@ -75,7 +75,7 @@ class IdentityHost(HostBase):
             self.a_t = torch.from_numpy(self.a).to(dev)
             self.b_t = torch.from_numpy(self.b).to(dev)
             self._digam_sum = {}
-        if self.comm.world == 1:                       # nothing to exchange: no staging buffer
+        if self.comm.solo:                       # nothing to exchange: no staging buffer
             self.rs_gam_t = rs_gam_local.reshape(-1)
             parts = [self.rs_gam_t.sum().reshape(1)]
             if omega:
@@ -281,7 +281,7 @@ class IdentityTail(IdentityHost):
     def _reduce_t(self, rs_gam_local, scalars_t):
         """ONE all-reduce of [rowSums(gam) (p) | scalars]; everything stays on the device."""
         import torch
-        if self.comm.world == 1:
+        if self.comm.solo:
             self.rs_gam_t = rs_gam_local.reshape(-1)
             out = scalars_t
         else:
@@ -437,7 +437,7 @@ class FusedTail(IdentityTail):
         self._last = (rs_gam_local, ent_local)
         st = self._sets[self._turn]
         self._turn ^= 1
-        world1 = self.comm.world == 1
+        world1 = self.comm.solo
         a = _lib.TailArgs()
         a.n, a.p, a.d_loc, a.d_total = self.n, self.p, self.tau_t.numel(), self.d
         a.a, a.b = self.a_t.data_ptr(), self.b_t.data_ptr()
@@ -828,12 +828,12 @@ def _gather(comm, local, d):
     """Concatenate the response shards (columns) of every rank, on every rank: ONE all-gather of
     the shards themselves (rank r contributes rows x d_r doubles; nothing is zero-padded or
     summed)."""
-    if comm.world == 1:
+    if comm.solo:
         return local
     return comm.all_gather_columns(np.asarray(local, dtype=np.float64), d)
 
 
 def _gather_vec(comm, local, d):
-    if comm.world == 1:
+    if comm.solo:
         return local
     return _gather(comm, np.asarray(local, dtype=np.float64).reshape(1, -1), d).reshape(-1)

@@ -245,7 +245,7 @@ class StructTail(StructHost):
         a.shard2, a.scal = self._buf[self.p:].data_ptr(), st["scal"].data_ptr()
         a.with_elbo, a.c_next, a.part = 1, 1.0, self._part.data_ptr()
         self._dvl.identity_tail(a, 0)                     # shard-local sums of elbo_struct_ (:201-221)
-        if self.comm.world == 1:
+        if self.comm.solo:
             self.rs_gam_t = rs_gam_local.reshape(-1)
         else:
             self._buf[: self.p].copy_(rs_gam_local.reshape(-1))

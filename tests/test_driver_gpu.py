@@ -643,6 +643,112 @@ def test_bench_two_ranks_share_the_gpu(hip):
     assert rec["config"]["elbo_monotone"]
 
 
+def _rccl_worker(port, q):
+    """ONE rank on the GPU with backend "nccl" (= RCCL): the group is created before any other GPU
+    call of this process, DistComm is forced through its collectives, so the RCCL branches of
+    comm.py (all-reduce enqueued on the stream without a drain, device-side all-gather) and the
+    packed all-reduce of FusedTail run as they do with N > 1 ranks."""
+    try:
+        import os
+        import sys
+        import torch
+        import torch.distributed as dist
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path[:0] = [here, os.path.dirname(here)]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        device = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        torch.cuda.set_device(device)
+        from oracle import ref_driver
+        from locus_amd.comm import DistComm
+        from locus_amd.locus_core import locus_core_
+        comm = DistComm(force_collectives=True)
+        assert dist.get_backend() == "nccl" and not comm.solo and not comm._sync_first
+        calls = {"ar": 0, "ag": 0}
+        ar, ag = dist.all_reduce, dist.all_gather_into_tensor
+
+        def count_ar(t, *a, **k):
+            assert t.is_cuda
+            calls["ar"] += 1
+            return ar(t, *a, **k)
+
+        def count_ag(o, i, *a, **k):
+            assert o.is_cuda and i.is_cuda
+            calls["ag"] += 1
+            return ag(o, i, *a, **k)
+        dist.all_reduce, dist.all_gather_into_tensor = count_ar, count_ag
+        sim, hyper, init, perm_fn = _setup(n=150, p=120, d=37, p0=9, seed=11)
+        kw = dict(tol=1e-30, maxit=3, perm_fn=perm_fn, full_output=True)
+        got = locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                          init["sig2_beta_vb"], init["tau_vb"], comm=comm, device=device, **kw)
+        assert calls["ar"] >= 3 and calls["ag"] >= 4, calls
+        ref = ref_driver.locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"],
+                                     init["mu_beta_vb"], init["sig2_beta_vb"], init["tau_vb"], **kw)
+        for k in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1", "tau_vb", "sig2_beta_vb"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+        assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+        assert np.array_equal(got["gam_vb"] > 0.5, ref["gam_vb"] > 0.5)
+        # all_gather_columns on its own, ragged in nothing (one rank) but through RCCL
+        loc = np.asfortranarray(np.random.default_rng(0).normal(size=(11, 7)))
+        np.testing.assert_array_equal(comm.all_gather_columns(loc, 7), loc)
+        dist.destroy_process_group()
+        q.put((0, None))
+    except BaseException as e:  # noqa: BLE001 -- report to the parent, which fails the test
+        import traceback
+        q.put((0, traceback.format_exc() + repr(e)))
+
+
+def test_identity_one_rank_over_rccl(oracle, hip):
+    """The RCCL code path on the one GPU: a child process whose first GPU call is
+    init_process_group("nccl", world_size=1, device_id=cuda:0) runs 3 iterations of locus_core_
+    through DistComm's collectives, against the oracle driver."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_worker, args=(port, q))
+    pr.start()
+    try:
+        rank, err = q.get(timeout=240)
+    finally:
+        pr.join(timeout=60)
+        if pr.is_alive():
+            pr.kill()
+    assert err is None, err
+
+
+def test_bench_one_rank_over_rccl(hip):
+    """bench.py through torch.distributed.run with ONE rank and LOCUS_BENCH_FORCE_DIST=1: the
+    "nccl" process group with device_id, DistComm and the packed all-reduce of every step."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, LOCUS_BENCH_FORCE_DIST="1", LOCUS_BENCH_WATCHDOG="120")
+    env.pop("LOCUS_HIP_SWEEP_CFG", None)
+    env.pop("LOCUS_BENCH_BACKEND", None)
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+         "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--p", "2000",
+         "--d", "1000", "--to-tol", "0"],
+        cwd=root, env=env, capture_output=True, text=True, timeout=220)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["config"]["collectives"] == "nccl (forced, 1 rank)"
+    assert rec["config"]["elbo_monotone"]
+
+
 @pytest.mark.parametrize("batch", ["x-y", "x", "0"])
 def test_identity_internal_batch_schemes(oracle, hip, batch):
     """The reference's internal schemes of locus_core_ (R/locus_core.R:97-161; "convergence not

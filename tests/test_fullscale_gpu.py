@@ -120,7 +120,13 @@ def test_full_length_chain_matches_oracle(oracle, hip, variant, n, p, d, sweeps,
         cur = dict(cur, **got)      # the HIP path continues from its OWN output
 
 
-ATOL_FULL = 1e-12   # absolute floor for full-length chains (see _assert_parity_full)
+ATOL_FULL = 5e-13   # absolute floor for full-length chains (see _assert_parity_full)
+
+
+def _max_loose(size):
+    """Entries allowed beyond the strict bar: what was observed (1 entry of 2.4 M, 1.75e-13 abs,
+    round 2) with a small margin -- not a percentage that grows into a licence."""
+    return max(4, int(2e-6 * size))
 
 
 def _assert_parity_full(got, ref, what):
@@ -130,8 +136,8 @@ def _assert_parity_full(got, ref, what):
     implementation (the literal restatement of src/coreLoop.cpp:40,50 included), and it enters every
     later dot product: an entry whose dot product cancels to < 1e-3 of its terms cannot agree to
     1e-9 RELATIVE between any two fp64 evaluation orders (the reference's own Eigen packet order
-    on another CPU included).  So: at most 1e-5 of the entries may miss the strict bar, and those
-    must still agree to ATOL_FULL = 1e-12 absolute (|mu| is typically 1e-2 .. 1); mat_x_m1 = Y -
+    on another CPU included).  So: at most max(4, 2e-6 of the entries) may miss the strict bar, and
+    those must still agree to ATOL_FULL = 5e-13 absolute (|mu| is typically 1e-2 .. 1); mat_x_m1 = Y -
     residual, a sum of p cancelling terms, is held to 1e-9 relative OR 1e-12 of its column's
     largest entry."""
     m_g, m_r = got["mat_x_m1"], ref["mat_x_m1"]
@@ -145,9 +151,9 @@ def _assert_parity_full(got, ref, what):
         err = np.abs(g - r)
         strict = err <= ATOL + RTOL * np.maximum(np.abs(g), np.abs(r))
         n_loose = int((~strict).sum())
-        assert n_loose <= 1e-5 * g.size, (
-            f"{what} {k}: {n_loose} / {g.size} entries miss rtol 1e-9 / atol 1e-13; max abs err "
-            f"{err.max():.3e}")
+        assert n_loose <= _max_loose(g.size), (
+            f"{what} {k}: {n_loose} / {g.size} entries miss rtol 1e-9 / atol 1e-13 (allowed "
+            f"{_max_loose(g.size)}); max abs err {err.max():.3e}")
         assert (err[~strict] <= ATOL_FULL).all(), (
             f"{what} {k}: cancelling entries differ by {err[~strict].max():.3e} > {ATOL_FULL}")
         if n_loose:

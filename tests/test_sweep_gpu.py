@@ -101,6 +101,87 @@ def test_bad_permutation_rejected(hip):
     assert np.array_equal(before, inp["gam_vb"])
 
 
+@pytest.mark.parametrize("cs,drop", [(2, 1), (3, 2), (2, 0)])
+def test_cluster_timeout_is_a_named_failure(oracle, hip, cs, drop, monkeypatch):
+    """A row-split cluster whose partner workgroup never runs (LOCUS_HIP_TEST_DROP_MEMBER makes
+    that member of every cluster return at entry, as if it had not been dispatched): the other
+    members give up after their bounded wait, the call fails with LOCUS_HIP_ETIMEOUT and its own
+    text -- not with the bad-permutation code --, the stateless entry point leaves the caller's
+    matrices alone, and the next, normal sweep is correct.  The reference's sweep cannot fail
+    half-way (src/coreLoop.cpp:36-52)."""
+    from locus_amd._lib import LocusHipError
+    inp = inputs_for("identity", 300, 53, 39, seed=4)
+    before = {k: np.array(inp[k], copy=True) for k in ("gam_vb", "beta_vb", "mat_x_m1", "mu_beta_vb")}
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-1,1,{cs},0")
+    monkeypatch.setenv("LOCUS_HIP_TEST_DROP_MEMBER", str(drop))
+    with pytest.raises(LocusHipError) as ei:
+        call_variant(hip, "identity", inp)
+    assert ei.value.code == -4, ei.value
+    assert "timed out" in str(ei.value) and "shuffled_ind" not in str(ei.value)
+    for k, v in before.items():
+        assert np.array_equal(v, inp[k]), k
+    monkeypatch.delenv("LOCUS_HIP_TEST_DROP_MEMBER")
+    ref = call_variant(oracle, "identity", inp)
+    got = call_variant(hip, "identity", inp)
+    assert_parity(got, ref, what=f"identity after a cluster time-out, CS = {cs}")
+
+
+def test_cluster_timeout_resident_state(hip, monkeypatch):
+    """The same failure through the device-resident API: Sweeper.status() raises ETIMEOUT, the
+    residual and the statistics are those from before the sweep (the documented contract), and
+    once the residual is rebuilt from the state a normal sweep equals a sweep from that state."""
+    import torch
+    from locus_amd import device as dv
+    from locus_amd._lib import LocusHipError
+    n, p, d = 300, 70, 37
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(n, p))
+    X = np.asfortranarray((X - X.mean(axis=0)) / X.std(axis=0, ddof=1))
+    Xd = dv.to_device_colmajor(X, dev)
+    px = dv.PackedX(Xd)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+    Y = up(rng.normal(size=(d, n))).t()
+    lo, l1 = up(np.full(p, -3.0) + rng.normal(scale=0.1, size=p)), up(np.full(p, -0.05))
+    tau = rng.gamma(2.0, 1.0, size=d)
+    s2 = 1.0 / ((n - 1 + 0.7) * tau)
+    cons = [up(s2 * tau), up(1 / (2 * s2)), up(-(np.log(tau) + np.log(0.7) + np.log(s2)) / 2), up(s2)]
+    perm = up(rng.permutation(p).astype(np.float64))
+    state = torch.empty((3, p, d), dtype=torch.float64, device=dev)
+    state[0], state[1] = up(rng.random((p, d)) ** 4), up(rng.normal(scale=0.3, size=(p, d)))
+    state[2] = state[0] * state[1]
+
+    def residual_of(st):
+        M = torch.empty((d, n), dtype=torch.float64, device=dev).t()
+        dv.gemm(n, d, p, px.Xp, 1, px.ld, st[2], d, 1, M, 1, n)
+        return dv.residual(Y, M)
+    R = residual_of(state)
+    R0 = R.clone()
+    stats = torch.full((4, d), -7.0, dtype=torch.float64, device=dev)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", "-1,1,2,0")
+    monkeypatch.setenv("LOCUS_HIP_TEST_DROP_MEMBER", "1")
+    sw = dv.Sweeper(px, d, dev)
+    sw.identity(perm, lo, l1, *cons, 1.0, R, state, stats)
+    with pytest.raises(LocusHipError) as ei:
+        sw.status()
+    assert ei.value.code == -4
+    assert torch.equal(R, R0) and bool((stats == -7.0).all())
+    monkeypatch.delenv("LOCUS_HIP_TEST_DROP_MEMBER")
+    # recover as documented: residual from the (partly updated) state, then sweep normally
+    st_a = state.clone()
+    st_a[2] = st_a[0] * st_a[1]
+    st_b = st_a.clone()
+    Ra, Rb = residual_of(st_a), residual_of(st_b)
+    sw.identity(perm, lo, l1, *cons, 1.0, Ra, st_a, stats)
+    sw.status()
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", "-1,1,1,0")      # one workgroup per tile: no clusters
+    sw1 = dv.Sweeper(px, d, dev)
+    sw1.identity(perm, lo, l1, *cons, 1.0, Rb, st_b, None)
+    sw1.status()
+    np.testing.assert_allclose(st_a.cpu().numpy(), st_b.cpu().numpy(), rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(Ra.cpu().numpy(), Rb.cpu().numpy(), rtol=1e-9, atol=1e-12)
+
+
 def test_two_sweeps_in_a_row_deterministic(hip):
     inp = inputs_for("identity", 200, 120, 20, seed=8)
     a = call_variant(hip, "identity", inp)
