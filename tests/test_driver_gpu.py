@@ -739,7 +739,7 @@ def test_bench_one_rank_over_rccl(hip):
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
          "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--p", "2000",
-         "--d", "1000", "--to-tol", "0"],
+         "--to-tol", "0"],
         cwd=root, env=env, capture_output=True, text=True, timeout=220)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
