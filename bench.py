@@ -24,6 +24,14 @@ The JSON line also carries
                  this fraction exceeds 1: the kernel is not HBM-bound.
   cpu_baseline : the C oracle (literal restatement of src/coreLoop.cpp, gcc -O2, 1 thread)
                  timed on this host on a bounded sample of the same workload.
+
+--config c2|c4|c5 (default c3 = the configuration the metric is quoted on) prints the same line
+for the other BASELINE.json configurations, each through its own driver:
+  c2  identity link   n = 1000, p = 20 000, d = 1000        locus_core_          coreLoop
+  c4  logistic link   n = 2000, p = 20 000, d = 500         locus_logit_core_    coreLogitLoop
+  c5  structured      n = 1000, p = 50 000, d = 2000        locus_struct_core_   coreStructLoop
+with the matching oracle routine as cpu_baseline and the matching flops per update
+(logit: 6 n + 70).
 """
 import argparse
 import json
@@ -38,17 +46,29 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak
+CONFIGS = {   # BASELINE.json `configs` [1..4]; model = driver, variant = oracle routine
+    "c2": dict(n=1000, p=20000, d=1000, model="identity", variant="identity", steps=100,
+               name="C2 identity-link"),
+    "c3": dict(n=1000, p=50000, d=10000, model="identity", variant="identity", steps=100,
+               name="C3 identity-link"),
+    "c4": dict(n=2000, p=20000, d=500, model="logit", variant="logit", steps=30,
+               name="C4 logistic-link (Jaakkola-Jordan bound)"),
+    "c5": dict(n=1000, p=50000, d=2000, model="struct", variant="struct", steps=30,
+               name="C5 structured (block-probit hotspot prior, blocks of 100 SNPs)"),
+}
 ELBO_ROUNDING_REL = 1e-12  # a converged ELBO may still move by this much of its magnitude (rounding)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=0, help="timed iterations (default 100; c4, c5: 30)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1000)
-    ap.add_argument("--p", type=int, default=50000)
-    ap.add_argument("--d", type=int, default=10000)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3",
+                    help="BASELINE.json configuration (default c3: the one the metric is quoted on)")
+    ap.add_argument("--n", type=int, default=0, help="override the configuration's n")
+    ap.add_argument("--p", type=int, default=0)
+    ap.add_argument("--d", type=int, default=0)
     ap.add_argument("--p0", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--to-tol", type=float, default=0.1,
@@ -57,7 +77,11 @@ def parse():
                          "(0 = skip)")
     ap.add_argument("--cpu-covariates", type=int, default=0,
                     help="covariates of the CPU sample (0 = sized for ~5 s per leg)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    a.n, a.p, a.d = a.n or cfg["n"], a.p or cfg["p"], a.d or cfg["d"]
+    a.steps = a.steps or cfg["steps"]
+    return a
 
 
 def make_data(n, p, d, p0, k_lo, k_hi, seed=123):
@@ -81,46 +105,65 @@ def make_data(n, p, d, p0, k_lo, k_hi, seed=123):
     return X, np.ascontiguousarray(Y[:, k_lo:k_hi].T), float(np.median(var))
 
 
-def cpu_baseline(n, d, ncov, seed=7):
-    """Oracle coreLoop (oracle/locus_oracle.c) on `ncov` covariates x all d responses: the
-    reference's single-threaded path, plus a best-effort all-cores line (the responses are
-    independent, so each thread runs the same routine on its own slice of the columns)."""
+KERNEL_NOTE = {
+    "identity": "coreLoop sweep = block packing + matrix-core sweep launches (mfma_sweep_kernel"
+                "<2,KT>: 32 responses per CU; the rest, and every shard of <= 16 responses per CU, "
+                "mfma_sweep1_kernel: one tile of 16 responses per cluster of 1-3 CUs)",
+    "struct": "coreStructLoop sweep = block packing + mfma_sweep1_kernel (one tile of 16 responses "
+              "per cluster of 1-3 CUs), per-covariate prior term log(1 - Phi) - log Phi",
+    "logit": "coreLogitLoop sweep = logit_la_kernel<NPL,CR> (one step of look-ahead, dedicated "
+             "chain wave; vector fp64)",
+}
+ORACLE_ROUTINE = {"identity": "coreLoop (src/coreLoop.cpp:19-54)",
+                  "logit": "coreLogitLoop (src/coreLoop.cpp:101-133)",
+                  "struct": "coreStructLoop (src/coreStructLoop.cpp:18-52)"}
+
+
+def cpu_baseline(n, d, ncov, seed=7, variant="identity"):
+    """The oracle routine of this configuration (oracle/locus_oracle.c: coreLoop, coreLogitLoop or
+    coreStructLoop) on `ncov` covariates x all d responses: the reference's single-threaded path,
+    plus a best-effort all-cores line (the responses are independent, so each thread runs the
+    same routine on its own slice of the columns)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle
     c_oracle.build()
     from locus_amd.simulate import sweep_inputs
     if ncov <= 0:
         # ~6 n d flop and ~5 passes over n x d doubles per covariate; aim at ~5 s per leg
-        probe = sweep_inputs(n, 4, d, seed=seed)
+        probe = sweep_inputs(n, 4, d, seed=seed, variant=variant)
         t0 = time.perf_counter()
-        _run_oracle(c_oracle, probe)
+        _run_oracle(c_oracle, probe, variant)
         per = (time.perf_counter() - t0) / 4
         ncov = int(max(4, min(4096, 5.0 / max(per, 1e-6))))
-    inp = sweep_inputs(n, ncov, d, seed=seed)
+    inp = sweep_inputs(n, ncov, d, seed=seed, variant=variant)
     t0 = time.perf_counter()
-    _run_oracle(c_oracle, inp)
+    _run_oracle(c_oracle, inp, variant)
     dt = time.perf_counter() - t0
 
     # all cores of this job's CPU share (OMP_NUM_THREADS on the GPU box), same sample again
     cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or os.cpu_count(),
                        os.cpu_count(), d))
-    inp = sweep_inputs(n, ncov, d, seed=seed)
+    inp = sweep_inputs(n, ncov, d, seed=seed, variant=variant)
     cuts = np.linspace(0, d, cores + 1).astype(int)
 
     def part(i):
         k0, k1 = cuts[i], cuts[i + 1]
         a = dict(inp)
-        for key in ("Y", "gam_vb", "beta_vb", "mat_x_m1", "mu_beta_vb"):
-            a[key] = inp[key][:, k0:k1]          # column slices of Fortran arrays: in place
-        for key in ("log_tau_vb", "sig2_beta_vb", "tau_vb"):
-            a[key] = inp[key][k0:k1]
-        _run_oracle(c_oracle, a)
+        for key in ("Y", "gam_vb", "beta_vb", "mat_x_m1", "mu_beta_vb", "mat_z_mu", "psi_vb"):
+            if key in inp:
+                a[key] = inp[key][:, k0:k1]      # column slices of Fortran arrays: in place
+        for key in ("log_tau_vb", "tau_vb"):
+            if key in inp:
+                a[key] = inp[key][k0:k1]
+        s2 = inp["sig2_beta_vb"]
+        a["sig2_beta_vb"] = s2[:, k0:k1] if s2.ndim == 2 else s2[k0:k1]
+        _run_oracle(c_oracle, a, variant)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(part, range(cores)))
     dt_all = time.perf_counter() - t0
     return dict(value=ncov * d / dt, unit="beta updates/s", cores=1, kind="port",
-                sample=f"oracle coreLoop (gcc -O2, 1 thread) on {ncov} covariates x all {d} "
+                sample=f"oracle {ORACLE_ROUTINE[variant]} (gcc -O2, 1 thread) on {ncov} covariates x all {d} "
                        f"responses, n={n} ({dt:.1f} s; cost per covariate does not depend on p); "
                        f"host has {os.cpu_count()} logical CPUs",
                 all_cores=dict(value=ncov * d / dt_all, cores=cores,
@@ -128,10 +171,19 @@ def cpu_baseline(n, d, ncov, seed=7):
                                     f"({dt_all:.1f} s)"))
 
 
-def _run_oracle(c_oracle, a):
-    c_oracle.coreLoop(a["X"], a["Y"], a["gam_vb"], a["log_om_vb"], a["log_1_min_om_vb"],
-                      a["log_sig2_inv_vb"], a["log_tau_vb"], a["beta_vb"], a["mat_x_m1"],
-                      a["mu_beta_vb"], a["sig2_beta_vb"], a["tau_vb"], a["shuffled_ind"], 1.0)
+def _run_oracle(c_oracle, a, variant="identity"):
+    if variant == "logit":
+        c_oracle.coreLogitLoop(a["X"], a["Y"], a["gam_vb"], a["log_om_vb"], a["log_1_min_om_vb"],
+                               a["log_sig2_inv_vb"], a["beta_vb"], a["mat_x_m1"], a["mat_z_mu"],
+                               a["mu_beta_vb"], a["psi_vb"], a["sig2_beta_vb"], a["shuffled_ind"])
+    elif variant == "struct":
+        c_oracle.coreStructLoop(a["X"], a["Y"], a["gam_vb"], a["log_om_vb"], a["log_1_min_om_vb"],
+                                a["log_sig2_inv_vb"], a["log_tau_vb"], a["beta_vb"], a["mat_x_m1"],
+                                a["mu_beta_vb"], a["sig2_beta_vb"], a["tau_vb"], a["shuffled_ind"])
+    else:
+        c_oracle.coreLoop(a["X"], a["Y"], a["gam_vb"], a["log_om_vb"], a["log_1_min_om_vb"],
+                          a["log_sig2_inv_vb"], a["log_tau_vb"], a["beta_vb"], a["mat_x_m1"],
+                          a["mu_beta_vb"], a["sig2_beta_vb"], a["tau_vb"], a["shuffled_ind"], 1.0)
 
 
 def committed_traffic(n, p, d_loc):
@@ -175,7 +227,6 @@ def main():
 
     from locus_amd import device as dv
     from locus_amd.comm import Comm, DistComm
-    from locus_amd.locus_core import FusedTail, IdentityEngine
     dv.require_gpu()
     # LOCUS_BENCH_FORCE_DIST=1 (launched through torch.distributed.run with ONE rank): the process
     # group, DistComm and the packed all-reduce of every step run as they do for N > 1 -- how a
@@ -192,6 +243,120 @@ def main():
     else:
         comm = Comm()
 
+    n, p, d, p0 = args.n, args.p, args.d, args.p0
+    k_lo, k_hi = comm.shard(d)
+    d_loc = k_hi - k_lo
+    cfg = CONFIGS[args.config]
+    if cfg["model"] == "identity":
+        lbs, dt, kern_ms, to_tol = run_identity(args, comm, device, dv, use_dist, rank)
+    else:
+        lbs, dt, kern_ms, to_tol = run_driver(args, cfg, comm, device, dv, use_dist)
+    if rank == 0:
+        report(args, cfg, world, backend, force_dist, use_dist, d_loc, lbs, dt, kern_ms, to_tol)
+    if use_dist:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def run_driver(args, cfg, comm, device, dv, use_dist):
+    """c4 / c5: the configuration's own driver (locus_logit_core_ / locus_struct_core_) on the
+    reference's simulation shape with the default hyper-parameters and initial values; a trace
+    hook brackets the K timed iterations (barrier + synchronize on both sides) after W warm-up
+    iterations of the same run, HIP events time the sweep call of every iteration."""
+    import torch
+    from locus_amd.prepare import add_intercept_, auto_set_hyper_, auto_set_init_
+    from locus_amd.simulate import simulate
+    n, p, d, p0 = args.n, args.p, args.d, args.p0
+    link = "logit" if cfg["model"] == "logit" else "identity"
+    sim = simulate(n, p, d, p0, seed=123, link=link)
+    X, Y = sim["X"], sim["Y"]
+    hy = auto_set_hyper_(Y, p, p0, link=link, struct=(cfg["model"] == "struct"))
+    ini = auto_set_init_(Y, p, p0, user_seed=123, link=link)
+    warm = max(1, args.warmup)
+    window = [True]                     # False: no timing window (the time-to-tolerance fit)
+    ev, marks = [], {}
+    orig = {name: getattr(dv.Sweeper, name) for name in ("identity", "logit")}
+
+    def timed(name):
+        def call(self, *a, **k):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig[name](self, *a, **k)
+            e1.record()
+            ev.append((e0, e1))
+        return call
+
+    class Trace(list):
+        def append(self, v):
+            it = v[0]
+            if window[0] and it == warm:
+                comm.barrier()
+                torch.cuda.synchronize()
+                ev.clear()
+                marks["t0"] = time.perf_counter()
+            if window[0] and it == warm + args.steps:
+                torch.cuda.synchronize()
+                comm.barrier()
+                marks["t1"] = time.perf_counter()
+                marks["ev"] = list(ev)
+            marks[it] = time.perf_counter()
+            super().append(v)
+
+    def fit(tol, maxit, trace):
+        kw = dict(tol=tol, maxit=maxit, trace=trace, comm=comm, device=device)
+        if cfg["model"] == "logit":
+            from locus_amd.locus_bin_core import locus_logit_core_
+            hy_l, ini_l = dict(hy), dict(ini)
+            Z = add_intercept_(n, d, hy_l, ini_l, link)
+            return locus_logit_core_(Y, X, Z, hy_l, ini_l["gam_vb"], ini_l["alpha_vb"],
+                                     ini_l["mu_beta_vb"], ini_l["sig2_alpha_vb"],
+                                     ini_l["sig2_beta_vb"], **kw)
+        from locus_amd.locus_struct_core import locus_struct_core_
+        from locus_amd.struct import set_struct
+        ls = set_struct(n, p, np.arange(1, p + 1, 100))
+        return locus_struct_core_(Y, X, hy, ini["gam_vb"], ini["mu_beta_vb"], ini["sig2_beta_vb"],
+                                  ini["tau_vb"], ls, **kw)
+
+    for name in orig:
+        setattr(dv.Sweeper, name, timed(name))
+    try:
+        trace = Trace()
+        fit(-1.0, warm + args.steps, trace)   # tol < 0: never "converged", exactly W + K iterations
+    finally:
+        for name, fn in orig.items():
+            setattr(dv.Sweeper, name, fn)
+    dt = marks["t1"] - marks["t0"]
+    if use_dist:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in marks["ev"]]))
+    lbs = [v[1] for v in trace]
+    to_tol = None
+    if args.to_tol > 0:
+        marks.clear()
+        window[0] = False
+        tr2 = Trace()
+        fit(args.to_tol, 1000, tr2)
+        n_it = len(tr2)
+        conv = n_it >= 2 and abs(tr2[-1][1] - tr2[-2][1]) < args.to_tol
+        per = dt / args.steps
+        to_tol = {"tol": args.to_tol, "iterations": n_it, "converged": bool(conv),
+                  "seconds": (marks[n_it] - marks[1]) + per,
+                  "note": "a second fit from the default initial values until |dELBO| < tol: time "
+                          "of its iterations 2.. by the clock plus one measured iteration for the "
+                          "first (whose set-up is not part of the metric)"}
+        lbs = [v[1] for v in tr2] if len(tr2) > len(lbs) else lbs
+    return lbs, dt, kern_ms, to_tol
+
+
+def run_identity(args, comm, device, dv, use_dist, rank):
+    """c2 / c3: the identity-link engine stepped directly (device-drawn initial values: at C3 the
+    p x d matrices hold 4 GB each)."""
+    import torch
+    from locus_amd.locus_core import FusedTail, IdentityEngine
     n, p, d, p0 = args.n, args.p, args.d, args.p0
     k_lo, k_hi = comm.shard(d)
     d_loc = k_hi - k_lo
@@ -287,7 +452,13 @@ def main():
                   "note": "iterations from the default initial values until |dELBO| < tol, at the "
                           "measured time per iteration"}
 
-    if rank == 0:
+    return lbs, dt, kern_ms, to_tol
+
+
+def report(args, cfg, world, backend, force_dist, use_dist, d_loc, lbs, dt, kern_ms, to_tol):
+    n, p, d, p0 = args.n, args.p, args.d, args.p0
+    logit = cfg["model"] == "logit"
+    if True:
         conv_tol = args.to_tol if args.to_tol > 0 else 0.1      # R/locus.R:243
         n_conv = next((i + 1 for i in range(1, len(lbs)) if abs(lbs[i] - lbs[i - 1]) < conv_tol),
                       len(lbs))
@@ -297,8 +468,10 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = p * d / (dt / args.steps)
         upd_launch = p * d_loc
-        bytes_per_update = 16.0 * n + 8.0 * n / d_loc + 32.0
-        flops_per_update = 4.0 * n + 60.0
+        # identity / struct 16 n + 8 n / d_loc + 32 B, 4 n + 60 flop; logit reads the
+        # psi column as well: 24 n + 8 n / d_loc + 40 B, 6 n + 70 flop
+        bytes_per_update = (24.0 if logit else 16.0) * n + 8.0 * n / d_loc + (40.0 if logit else 32.0)
+        flops_per_update = (6.0 if logit else 4.0) * n + (70.0 if logit else 60.0)
         ach_gbs = upd_launch * bytes_per_update / (kern_ms * 1e-3) / 1e9
         ach_tf = upd_launch * flops_per_update / (kern_ms * 1e-3) / 1e12
         out = {
@@ -306,8 +479,9 @@ def main():
             "unit": "beta updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C3 identity-link CAVI iteration n={n} p={p} d={d} p0_av={p0}"
+            "config": {"workload": f"{cfg['name']} CAVI iteration n={n} p={p} d={d} p0_av={p0}"
                                    f" (d sharded over {world} GPU(s), X replicated)",
+                       "name": args.config,
                        "n": n, "p": p, "d": d, "d_per_gpu": d_loc,
                        "parallelism": f"d-shard x{world}",
                        "collectives": (f"{backend} (forced, 1 rank)" if force_dist and world == 1
@@ -326,10 +500,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
                          "traffic": committed_traffic(n, p, d_loc),
-                         "kernel": "coreLoop sweep = block packing + matrix-core sweep launches "
-                                   "(mfma_sweep_kernel<2,KT>: 32 responses per CU; the rest, and "
-                                   "every shard of <= 16 responses per CU, mfma_sweep1_kernel: one "
-                                   "tile of 16 responses per cluster of 1-2 CUs)",
+                         "kernel": KERNEL_NOTE[cfg["model"]],
                          "kernel_ms": kern_ms,
                          "flops_per_update": flops_per_update, "updates_per_launch": upd_launch,
                          "note": "traffic = PMC-measured HBM bytes of one sweep (profiles/)"},
@@ -343,12 +514,13 @@ def main():
         }
         if to_tol is not None:
             out["time_to_elbo_tol"] = to_tol
+        if logit:
+            out["roofline"]["note"] += ("; the logit sweep is vector fp64 (its Gram matrix depends "
+                                        "on the response: no matrix-core role), priced against the "
+                                        "same 78.6 TFLOP/s that bounds fp64 VALU and MFMA alike")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_covariates)
+            out["cpu_baseline"] = cpu_baseline(n, d, args.cpu_covariates, variant=cfg["variant"])
         print(json.dumps(out), flush=True)
-    if use_dist:
-        import torch.distributed as dist
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -253,11 +253,13 @@ int locus_hip_gemm_dev(int64_t m, int64_t n, int64_t k, double alpha, const doub
  *   mu = (T + (n-1) beta) * fac_k ; gam = exp(-log1pexp(...)) ; beta = mu * gam.
  * fac, hinv, cstk are [d]: fac = sig2_beta_k tau_k (probit: sig2_beta),
  * hinv = 1/(2 sig2_beta_k), cstk = log_tau_k/2 + log(sig2_beta_k)/2 (probit: log(sig2_beta)/2
- * with probit = 1, which also changes the order of the additions, :94-95). */
+ * with probit = 1, which also changes the order of the additions, :94-95).  cfac = 1 for
+ * coreBatch; the driver's internal scheme "x" (R/locus_core.R:104-111) anneals with
+ * cfac = c multiplying the argument of log_one_plus_exp_ (fac then carries c as well). */
 int locus_hip_batch_update_dev(double* state, const double* lo, const double* l1,
                                const double* fac, const double* hinv, const double* cstk,
-                               double log_sig2_inv, double nm1, int probit, int64_t p,
-                               int64_t d, void* stream);
+                               double log_sig2_inv, double nm1, double cfac, int probit,
+                               int64_t p, int64_t d, void* stream);
 
 /* ---- binary-response drivers (logit / probit): device side of R/locus_logistic_core.R and
  * R/locus_probit_core.R around the sweep.  n x d matrices column-major, [p][d] / [q][d]

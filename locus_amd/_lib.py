@@ -87,8 +87,8 @@ SIGNATURES = {
     "locus_hip_state_cols_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr]),
     "locus_hip_gemm_dev": (_int, [_i64, _i64, _i64, _dbl, _ptr, _i64, _i64, _int, _ptr, _i64, _i64,
                                   _int, _dbl, _ptr, _i64, _i64, _ptr]),
-    "locus_hip_batch_update_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _dbl, _int,
-                                          _i64, _i64, _ptr]),
+    "locus_hip_batch_update_dev": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _dbl, _dbl, _dbl,
+                                          _int, _i64, _i64, _ptr]),
     "locus_hip_m2_minus_b2_dev": (_int, [_ptr, _ptr, _dbl, _ptr, _i64, _i64, _ptr]),
     "locus_hip_s2_from_xwx_dev": (_int, [_ptr, _dbl, _ptr, _i64, _ptr]),
     "locus_hip_half_log_dev": (_int, [_ptr, _ptr, _i64, _ptr]),

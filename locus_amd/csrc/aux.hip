@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) batch_update_kernel(double* __restrict__ 
                                                            const double* __restrict__ hinv,
                                                            const double* __restrict__ cstk,
                                                            double log_sig2_inv, double nm1,
-                                                           int probit, int p, int d)
+                                                           double cfac, int probit, int p, int d)
 {
     const size_t pd = (size_t)p * d;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < pd;
@@ -311,8 +311,10 @@ __global__ void __launch_bounds__(256) batch_update_kernel(double* __restrict__ 
         const double m = probit ? fac[k] * t : t * fac[k];
         const double q = -(m * m) * hinv[k];
         const double lod = l1[j] - lo[j];
-        const double a = probit ? (((q + lod) - log_sig2_inv / 2) - cstk[k])
-                                : (((q - cstk[k]) + lod) - log_sig2_inv / 2);
+        // cfac: annealing factor of the internal scheme "x" (R/locus_core.R:104-111: c multiplies
+        // the whole argument; fac already carries it); coreBatch itself has none (cfac == 1)
+        const double a = cfac * (probit ? (((q + lod) - log_sig2_inv / 2) - cstk[k])
+                                        : (((q - cstk[k]) + lod) - log_sig2_inv / 2));
         const double ex = exp(-fabs(a));
         const double g = ((a >= 0.0) ? ex : 1.0) / (1.0 + ex);
         state[e] = g;
@@ -323,12 +325,12 @@ __global__ void __launch_bounds__(256) batch_update_kernel(double* __restrict__ 
 
 int batch_update(double* state, const double* lo, const double* l1, const double* fac,
                  const double* hinv, const double* cstk, double log_sig2_inv, double nm1,
-                 int probit, int p, int d, hipStream_t st)
+                 double cfac, int probit, int p, int d, hipStream_t st)
 {
     const size_t pd = (size_t)p * d;
     const unsigned blocks = (unsigned)std::min<size_t>((pd + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(batch_update_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, state, lo,
-                       l1, fac, hinv, cstk, log_sig2_inv, nm1, probit, p, d);
+                       l1, fac, hinv, cstk, log_sig2_inv, nm1, cfac, probit, p, d);
     LOCUS_HIP_CHECK(hipGetLastError());
     return 0;
 }

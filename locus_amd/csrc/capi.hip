@@ -441,7 +441,7 @@ int run_batch(int probit, const double* X, const double* Y, double* gam, const d
     if ((rc = upload(dhinv, h_hinv.data(), (size_t)d))) return rc;
     if ((rc = upload(dcstk, h_cstk.data(), (size_t)d))) return rc;
     if ((rc = batch_update(dstate.d(), dlo.d(), dl1.d(), dfac.d(), dhinv.d(), dcstk.d(),
-                           log_sig2_inv, (double)(n - 1), probit, (int)p, (int)d, st)))
+                           log_sig2_inv, (double)(n - 1), 1.0, probit, (int)p, (int)d, st)))
         return rc;
     // mat_x_m1 = X beta  (n x d column-major) from the new beta plane
     {
@@ -721,13 +721,14 @@ int locus_hip_gemm_dev(int64_t m, int64_t n, int64_t k, double alpha, const doub
 
 int locus_hip_batch_update_dev(double* state, const double* lo, const double* l1, const double* fac,
                                const double* hinv, const double* cstk, double log_sig2_inv,
-                               double nm1, int probit, int64_t p, int64_t d, void* stream)
+                               double nm1, double cfac, int probit, int64_t p, int64_t d,
+                               void* stream)
 {
     LOCUS_REQUIRE(state && lo && l1 && fac && hinv && cstk && p >= 1 && d >= 1 && p < (1ll << 31) &&
                       d < (1ll << 31),
                   "batch_update: bad arguments");
-    return batch_update(state, lo, l1, fac, hinv, cstk, log_sig2_inv, nm1, probit, (int)p, (int)d,
-                        (hipStream_t)stream);
+    return batch_update(state, lo, l1, fac, hinv, cstk, log_sig2_inv, nm1, cfac, probit, (int)p,
+                        (int)d, (hipStream_t)stream);
 }
 
 // ---- binary-response drivers ------------------------------------------------------

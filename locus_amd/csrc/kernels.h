@@ -18,7 +18,7 @@ int state_cols(double* state, const double* s2k, const double* s2jk, double* st_
 
 int batch_update(double* state, const double* lo, const double* l1, const double* fac,
                  const double* hinv, const double* cstk, double log_sig2_inv, double nm1,
-                 int probit, int p, int d, hipStream_t st);
+                 double cfac, int probit, int p, int d, hipStream_t st);
 
 // binary-response drivers (link.hip)
 int m2_minus_b2(const double* state, const double* s2jk, double s2c, double* D, size_t pd,

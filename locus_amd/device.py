@@ -160,10 +160,10 @@ def gemm(m, n, k, A, sa_m, sa_k, B, sb_k, sb_n, C, sc_m, sc_n, alpha=1.0, beta=0
     return C
 
 
-def batch_update(state, lo, l1, fac, hinv, cstk, log_sig2_inv, nm1, probit, p, d):
+def batch_update(state, lo, l1, fac, hinv, cstk, log_sig2_inv, nm1, probit, p, d, cfac=1.0):
     _lib.check(_lib.lib().locus_hip_batch_update_dev(_p(state), _p(lo), _p(l1), _p(fac), _p(hinv),
                                                      _p(cstk), float(log_sig2_inv), float(nm1),
-                                                     int(probit), p, d, _stream()))
+                                                     float(cfac), int(probit), p, d, _stream()))
 
 
 # ---- binary-response drivers (link.hip) ---------------------------------------------------

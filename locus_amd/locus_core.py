@@ -616,15 +616,17 @@ class IdentityEngine:
             prm = host.begin_iteration(c)
         up = self._up
         if scheme in ("x", "x-y"):
-            if float(c) != 1.0:
-                raise NotImplementedError("annealing with the batched schemes: the element-wise "
-                                          "kernel of coreBatch has no annealing factor")
+            # "x" anneals (R/locus_core.R:104-111: c scales mu_beta_vb and the argument of
+            # log_one_plus_exp_); "x-y" = coreBatch has no annealing factor and locus_core_
+            # refuses that combination up front (:123-124)
+            if scheme == "x-y" and float(c) != 1.0:
+                raise ValueError("Annealing not implemented for this scheme. Exit.")
             log_si = float(prm["log_sig2_inv_vb"])
             # T = X'(Y - mat_x_m1) into the mu plane, then mu, gam, beta element-wise
             dv.gemm(p, d, n, self.px.Xp, self.px.ld, 1, self.R, 1, n, self.state[1], d, 1)
             cstk = -up(prm["cst"]) - log_si / 2              # log_tau / 2 + log(sig2_beta) / 2
             dv.batch_update(self.state, up(prm["lo"]), up(prm["l1"]), up(prm["scale"]),
-                            up(prm["hinv"]), cstk, log_si, n - 1, 0, p, d)
+                            up(prm["hinv"]), cstk, log_si, n - 1, 0, p, d, cfac=float(c))
             M = t.empty((d, n), dtype=t.float64, device=self.device).t()
             dv.gemm(n, d, p, self.px.Xp, 1, self.px.ld, self.state[2], d, 1, M, 1, n)
             self.R = dv.residual(self.Y, M)

@@ -148,6 +148,32 @@ def test_identity_annealing(oracle, hip):
     assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
 
 
+def test_identity_scheme_x_anneals(oracle, hip):
+    """batch = "x" with an annealing ladder (R/locus_core.R:104-111 carry c; only "x-y" refuses
+    annealing, :123-124): the element-wise kernel of coreBatch with the factor c."""
+    from oracle import ref_driver
+    from locus_amd.locus_core import locus_core_
+    sim, hyper, init, perm_fn = _setup(n=90, p=40, d=6, p0=5, seed=3)
+    kt = {}
+
+    def k_perm_fn(it):
+        if it not in kt:
+            kt[it] = np.random.default_rng(100 + it).permutation(6)
+        return kt[it]
+    kw = dict(tol=1e-30, maxit=6, perm_fn=perm_fn, anneal=(1, 2.0, 4), full_output=True, batch="x",
+              debug=False, k_perm_fn=k_perm_fn)
+    ref = ref_driver.locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                                 init["sig2_beta_vb"], init["tau_vb"], **kw)
+    got = locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                      init["sig2_beta_vb"], init["tau_vb"], **kw)
+    for key in ("gam_vb", "mu_beta_vb", "beta_vb", "mat_x_m1"):
+        np.testing.assert_allclose(got[key], ref[key], rtol=1e-9, atol=1e-12, err_msg=key)
+    assert abs(got["lb_opt"] - ref["lb_opt"]) <= 1e-8 * abs(ref["lb_opt"])
+    with pytest.raises(ValueError):
+        locus_core_(sim["Y"], sim["X"], hyper, init["gam_vb"], init["mu_beta_vb"],
+                    init["sig2_beta_vb"], init["tau_vb"], **dict(kw, batch="x-y"))
+
+
 # ---- structured model (R/locus_struct_core.R) ---------------------------------------------
 def _setup_struct(n=200, p=500, d=20, p0=15, bl=50, seed=5):
     from locus_amd.prepare import auto_set_hyper_, auto_set_init_
