@@ -1,7 +1,9 @@
 // Host side of the matrix-core sweep: per-sweep block packing of X and launch dispatch.
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -14,6 +16,9 @@ int launch_mfma_sweep_t2(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStr
 int launch_mfma_sweep1_c1(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
 int launch_mfma_sweep1_c2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
 int launch_mfma_sweep1_c3(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c2t2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c3t2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c4t2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
 
 // ---------------------------------------------------------------------------
 // Block packing for mfma_sweep1_kernel (look-ahead of L blocks, NW = CS * 6 row groups).  One
@@ -274,14 +279,19 @@ int mfma_kt_for(int64_t n, int T)
 
 // bytes of the block-packed operands for a sweep over p covariates of n rows
 // 16-row tiles per matrix wave of mfma_sweep1_kernel for n rows cut over CS workgroups
-int mfma1_kt_for(int64_t n, int CS)
+// (T = tiles of 16 responses per cluster: 1, or 2 with CS = 2, 3, 4)
+int mfma1_kt_for(int64_t n, int CS, int T = 1)
 {
 #define LOCUS_KT_ITEM(k) k,
     static const int kts1[] = {LOCUS_MFMA_KTS_T1(LOCUS_KT_ITEM) 0};
     static const int kts2[] = {LOCUS_MFMA1_KTS_C2(LOCUS_KT_ITEM) 0};
     static const int kts3[] = {LOCUS_MFMA1_KTS_C3(LOCUS_KT_ITEM) 0};
+    static const int ktsT2[] = {LOCUS_MFMA1_KTS_T2(LOCUS_KT_ITEM) 0};
 #undef LOCUS_KT_ITEM
-    for (const int* kt = (CS == 1) ? kts1 : (CS == 2 ? kts2 : kts3); *kt; ++kt)
+    if (T == 2 && (CS < 2 || CS > 4)) return 0;
+    if (T == 1 && (CS < 1 || CS > 3)) return 0;
+    if (n > 2016) return 0;  // the matrix-core sweep's limit (mfma_kt_for)
+    for (const int* kt = (T == 2) ? ktsT2 : (CS == 1) ? kts1 : (CS == 2 ? kts2 : kts3); *kt; ++kt)
         if ((int64_t)CS * 6 * 16 * *kt >= n) return *kt;
     return 0;
 }
@@ -289,16 +299,17 @@ int mfma1_kt_for(int64_t n, int CS)
 // doubles of the mfma_sweep1_kernel layout for `nblk` blocks (largest look-ahead, both CS)
 static size_t mfma1_layout_doubles(int64_t n, size_t nblk, int cus)
 {
-    const int kt1 = mfma1_kt_for(n, 1), kt2 = mfma1_kt_for(n, 2), kt3 = mfma1_kt_for(n, 3);
     const size_t nit = nblk + 5;
-    const size_t rows_pad = std::max(std::max((size_t)6 * 16 * kt1, (size_t)2 * 6 * 16 * kt2),
-                                     (size_t)3 * 6 * 16 * kt3);
+    size_t rows_pad = 0;
+    for (int T = 1; T <= 2; ++T)
+        for (int CS = 1; CS <= 4; ++CS)
+            rows_pad = std::max(rows_pad, (size_t)CS * 6 * 16 * mfma1_kt_for(n, CS, T));
     return nit * rows_pad * 32 + 2048      // XS (+ read-ahead slack)
            + nit * 256                     // cg
            + 4 * (nit + 1) * 256           // ax, lags 1..4
            + 16 * nit * 2 + 256            // sc2
            + 8 * nit + 256                 // jidx (ints)
-           + (size_t)cus * (xbuf_tile_words(2) / 2) + 256   // xbuf: <= cus members in flight
+           + (size_t)cus * (xbuf_tile_words(2, 2) / 2) + 256   // xbuf: <= cus members in flight
            + (size_t)cus * 16 + 256;       // xflag (32 ints per member)
 }
 
@@ -408,10 +419,14 @@ static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, i
 // One launch sequence of mfma_sweep1_kernel over responses [k_begin, k_end): packs (if `pack`) and
 // launches clusters of CS workgroups, at most as many clusters per launch as are resident at once
 // (a cluster's members wait for each other, so every member must be on a CU at the same time).
-static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin, int k_end, bool pack,
-                            void* xb_ws, size_t xb_bytes, hipStream_t st)
+static int pack_and_launch1(const SweepParams& prm, int T, int CS, int KT, int k_begin, int k_end,
+                            bool pack, void* xb_ws, size_t xb_bytes, hipStream_t st)
 {
     const int L = mfma1_lag(CS);
+    if (!((T == 1 && CS >= 1 && CS <= 3) || (T == 2 && CS >= 2 && CS <= 4))) {
+        set_error("mfma sweep: no kernel for this (tiles per cluster, cluster size)");
+        return LOCUS_HIP_EUNSUPPORTED;
+    }
     const int NW = CS * 6;
     const int rows_pad = NW * 16 * KT;
     if (KT <= 0 || rows_pad < prm.n) {
@@ -430,7 +445,7 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
     double* sc2 = axp + 4 * (nit + 1) * 256;
     int* jidx = reinterpret_cast<int*>(sc2 + 16 * nit * 2 + 256);
     unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(jidx) + 8 * nit + 256;
-    int* xflag = reinterpret_cast<int*>(xbuf + (size_t)cus * (xbuf_tile_words(2) / 2) + 256);
+    int* xflag = reinterpret_cast<int*>(xbuf + (size_t)cus * (xbuf_tile_words(2, 2) / 2) + 256);
     const size_t used = (size_t)(reinterpret_cast<char*>(xflag) - static_cast<char*>(xb_ws)) +
                         sizeof(int) * ((size_t)cus * 32 + 64);
     if (used > xb_bytes) {
@@ -470,19 +485,26 @@ static int pack_and_launch1(const SweepParams& prm, int CS, int KT, int k_begin,
         set_error("mfma sweep: too few CUs for row-split clusters");
         return LOCUS_HIP_EUNSUPPORTED;
     }
-    for (int k = k_begin; k < k_end; k += 16 * max_tiles) {
-        const int ke = std::min(k_end, k + 16 * max_tiles);
+    const int TW = 16 * T;  // responses per cluster
+    for (int k = k_begin; k < k_end; k += TW * max_tiles) {
+        const int ke = std::min(k_end, k + TW * max_tiles);
         mp.k_begin = k; mp.k_end = ke;
-        mp.ntiles = (ke - k + 15) / 16;
+        mp.ntiles = (ke - k + TW - 1) / TW;
         if (CS > 1) {  // a granule / flag is valid when it carries this launch's tag: start from zero
             LOCUS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * mp.ntiles *
-                                                        xbuf_tile_words(CS), st));
+                                                        xbuf_tile_words(CS, T), st));
             LOCUS_HIP_CHECK(hipMemsetAsync(xflag, 0, sizeof(int) * (size_t)mp.ntiles * CS * 32, st));
         }
         dim3 grid((unsigned)(((mp.ntiles + 7) / 8) * 8 * CS));
-        const int rc = (CS == 1)   ? launch_mfma_sweep1_c1(mp, KT, grid, st)
-                       : (CS == 2) ? launch_mfma_sweep1_c2(mp, KT, grid, st)
-                                   : launch_mfma_sweep1_c3(mp, KT, grid, st);
+        int rc;
+        if (T == 2)
+            rc = (CS == 2)   ? launch_mfma_sweep1_c2t2(mp, KT, grid, st)
+                 : (CS == 3) ? launch_mfma_sweep1_c3t2(mp, KT, grid, st)
+                             : launch_mfma_sweep1_c4t2(mp, KT, grid, st);
+        else
+            rc = (CS == 1)   ? launch_mfma_sweep1_c1(mp, KT, grid, st)
+                 : (CS == 2) ? launch_mfma_sweep1_c2(mp, KT, grid, st)
+                             : launch_mfma_sweep1_c3(mp, KT, grid, st);
         if (rc) return rc;
     }
     return 0;
@@ -513,12 +535,64 @@ static int choose_cs(int n, int tiles)
     return (kt2 > 0 && t8 * 2 <= cus) ? 2 : 1;
 }
 
-// cfg: C = T (tiles of 16 responses per workgroup; 0 = plan by d), G = KT (16-row tiles per matrix
-// wave, 0 = smallest instantiated value that covers n).
-// Planned mode: a workgroup holds its responses in the registers of a whole CU, so one launch
-// takes at most 32 (T = 2) or 16 (T = 1) responses per CU.  Measured at n = 1000 (MI355X): a T = 2
-// launch costs ~1.4x a T = 1 launch, so responses go to T = 2 launches while more than one T = 1
-// launch's worth is left, and the remainder to T = 1.
+// ---------------------------------------------------------------------------
+// Launch plan.  A launch's duration does not depend on how many of its workgroups are busy --
+// every cluster walks the same p covariates -- but on what bounds one block of 16 steps in its
+// geometry (cycles, measured at n = 1000 on MI355X and extended in KT, the 16-row tiles per matrix
+// wave):
+//   matrix work   two matrix waves per SIMD x 8 KT T MFMAs of 64 cycles        = 1024 KT T
+//   operand fetch six waves x 8 KT operands of 512 B through the CU's L1 at ~20 B/clk = 1229 KT
+//   chain         16 dependent updates, ~5600 alone, ~6500 with the cluster hand-over
+//   A (mfma_sweep_kernel<2, KT>: 32 responses on ONE CU, 7 matrix waves, the chain shares a SIMD
+//      with one of them): 2048 KT + 2300
+// Geometries: A; one tile of 16 responses on 1, 2, 3 CUs; two tiles (32 responses) on 2, 3, 4
+// CUs.  Members of a cluster must all be resident, so a cluster launch takes at most
+// floor(CUs / 8 CS) 8 clusters.  The plan minimises the sum of the launch durations over all ways
+// of covering d responses (dynamic programme over units of 16 responses); every launch re-packs
+// the block operands for its row tiling (~400 cycles per block).
+// ---------------------------------------------------------------------------
+struct LaunchType {
+    int T, CS;      // CS = 0: mfma_sweep_kernel<2, KT> (one workgroup per 32 responses)
+    int KT;
+    int cap;        // responses one launch takes
+    double cost;    // cycles per block of 16 steps
+};
+
+static std::vector<LaunchType> launch_types(int n)
+{
+    std::vector<LaunchType> v;
+    const int cus = device_cus(), ccus = cluster_cus();
+    int only_cs = 0, only_t = 0;
+    if (const char* e = getenv("LOCUS_HIP_MFMA_CS")) {  // one tile per cluster of that size only
+        only_cs = atoi(e);
+        only_t = 1;
+    }
+    if (const char* e = getenv("LOCUS_HIP_MFMA_PLAN")) {  // "T,CS": that cluster geometry only
+        int t = 0, c = 0;
+        if (sscanf(e, "%d,%d", &t, &c) == 2) { only_t = t; only_cs = c; }
+    }
+    const double pack = 400.0;
+    if (const int kt = mfma_kt_for(n, 2); kt > 0 && (only_t == 0 || only_t == 1))
+        v.push_back({2, 0, kt, 32 * cus, 2048.0 * kt + 2300.0 + pack});
+    for (int T = 1; T <= 2; ++T)
+        for (int CS = (T == 1 ? 1 : 2); CS <= (T == 1 ? 3 : 4); ++CS) {
+            if (only_t != 0 && (T != only_t || CS != only_cs)) continue;
+            const int kt = mfma1_kt_for(n, CS, T);
+            const int c = (CS == 1) ? cus : ccus;
+            if (kt == 0 || (CS > 1 && c < 8 * CS)) continue;
+            const int clusters = (CS == 1) ? c : (c / (8 * CS)) * 8;
+            const double chain = (CS == 1) ? 5600.0 : 6500.0;
+            const double work = std::max(1024.0 * kt * T, 1229.0 * kt);
+            v.push_back({T, CS, kt, 16 * T * clusters, std::max(work, chain) + 500.0 + pack});
+        }
+    return v;
+}
+
+// cfg: C = T (tiles of 16 responses per cluster; 0 = plan by d), S = workgroups per cluster,
+// G = KT (16-row tiles per matrix wave, 0 = smallest instantiated value that covers n).
+//   C = 1: mfma_sweep1_kernel<KT, S>, S = 1, 2, 3 (0 = chosen from d; anything else = 1);
+//   C = 2: S = 2, 3, 4: mfma_sweep1_kernel<KT, S, 2> (two tiles per cluster);
+//          any other S: mfma_sweep_kernel<2, KT> (two tiles on one workgroup).
 int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
                    hipStream_t st)
 {
@@ -531,35 +605,50 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
         const int CS = (cfg.S == 2 || cfg.S == 3) ? cfg.S
                                                   : (cfg.S == 0 ? choose_cs(prm.n, (prm.d + 15) / 16) : 1);
         const int KT = cfg.G > 0 ? cfg.G : mfma1_kt_for(prm.n, CS);
-        return pack_and_launch1(prm, CS, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
+        return pack_and_launch1(prm, 1, CS, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
+    }
+    if (cfg.C == 2 && cfg.S >= 2 && cfg.S <= 4) {
+        const int KT = cfg.G > 0 ? cfg.G : mfma1_kt_for(prm.n, cfg.S, 2);
+        return pack_and_launch1(prm, 2, cfg.S, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
     }
     if (cfg.C != 0) {
         const int KT = cfg.G > 0 ? cfg.G : mfma_kt_for(prm.n, cfg.C);
         return pack_and_launch(prm, cfg.C, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
     }
-    const int kt1 = mfma_kt_for(prm.n, 1), kt2 = mfma_kt_for(prm.n, 2);
-    if (kt1 == 0) {
+    if (mfma_kt_for(prm.n, 1) == 0) {
         set_error("mfma sweep: n too large for the matrix-core kernel");
         return LOCUS_HIP_EUNSUPPORTED;
     }
-    const int cus = device_cus();
-    const int cap1 = 16 * cus, cap2 = 32 * cus;
-    int k = 0, last_T = 0;
-    while (k < prm.d) {
-        const int rem = prm.d - k;
-        const int T = (kt2 > 0 && rem > cap1) ? 2 : 1;
-        const int take = std::min(rem, T == 2 ? cap2 : cap1);
-        int rc;
-        if (T == 2) {
-            rc = pack_and_launch(prm, 2, kt2, k, k + take, T != last_T, xb_ws, xb_bytes, st);
-        } else {
-            const int CS = choose_cs(prm.n, (take + 15) / 16);
-            rc = pack_and_launch1(prm, CS, mfma1_kt_for(prm.n, CS), k, k + take, true, xb_ws, xb_bytes,
-                                  st);
+    const std::vector<LaunchType> types = launch_types(prm.n);
+    if (types.empty()) {
+        set_error("mfma sweep: no launch geometry for this shape");
+        return LOCUS_HIP_EUNSUPPORTED;
+    }
+    // best[u] = cheapest cover of u units of 16 responses
+    const int U = (prm.d + 15) / 16;
+    std::vector<double> best((size_t)U + 1, 0.0);
+    std::vector<int> pick((size_t)U + 1, -1);
+    for (int u = 1; u <= U; ++u) {
+        best[u] = 1e300;
+        for (size_t t = 0; t < types.size(); ++t) {
+            const int c = std::max(1, types[t].cap / 16);
+            const double v = types[t].cost + best[std::max(0, u - c)];
+            if (v < best[u]) { best[u] = v; pick[u] = (int)t; }
         }
+    }
+    int k = 0, last = -1;
+    for (int u = U; u > 0;) {
+        const LaunchType& lt = types[pick[u]];
+        const int take = std::min(prm.d - k, lt.cap);
+        const bool pack = pick[u] != last;  // consecutive launches of one geometry share the operands
+        const int rc = (lt.CS == 0)
+                           ? pack_and_launch(prm, 2, lt.KT, k, k + take, pack, xb_ws, xb_bytes, st)
+                           : pack_and_launch1(prm, lt.T, lt.CS, lt.KT, k, k + take, pack, xb_ws, xb_bytes,
+                                              st);
         if (rc) return rc;
-        last_T = T;
+        last = pick[u];
         k += take;
+        u -= std::max(1, lt.cap / 16);
     }
     return 0;
 }

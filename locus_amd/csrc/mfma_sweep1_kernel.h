@@ -1,4 +1,4 @@
-// Matrix-core CAVI sweep for ONE tile of 16 responses per cluster of CS workgroups
+// Matrix-core CAVI sweep for ONE tile of 16 T responses (T = 1, 2) per cluster of CS workgroups
 // (coreLoop / coreZLoop / coreStructLoop / coreProbitLoop, src/coreLoop.cpp:36-52,
 // coreStructLoop.cpp:34-50) -- the latency regime: d_loc <= 16 responses per CU (C2, C5, the
 // remainder of C3 on one GPU, every multi-GPU shard).
@@ -59,9 +59,9 @@ struct Mfma1Params {
     double* state;        // [3][p][d]
     double* st;           // [4][d] or nullptr
     // CS > 1: exchange of the members' partial G tiles, [ntiles][kXTile] 8-byte words per cluster:
-    // kXRing slots x CS members x 512 granules {32 bits of a double, tag = block + 1} (zeroed by the
-    // host before every launch: a granule is valid when its tag matches), then CS x 64 doubles for
-    // the members' sums of squares of the residual at the end of the sweep
+    // kXRing slots x CS members x T x 512 granules {32 bits of a double, tag = block + 1} (zeroed by
+    // the host before every launch: a granule is valid when its tag matches), then CS x T x 64
+    // doubles for the members' sums of squares of the residual at the end of the sweep
     unsigned long long* xbuf;
     int* xflag;           // CS > 1: [ntiles][CS][32] end-of-sweep flags of the members
     int drop_member;      // test hook (LOCUS_HIP_TEST_DROP_MEMBER): this member of every cluster
@@ -69,11 +69,14 @@ struct Mfma1Params {
 };
 
 constexpr int kXRing = 16;  // exchange slots per member; >= 2 L + 1 blocks can be in flight
-__host__ __device__ constexpr size_t xbuf_tile_words(int CS) { return (size_t)kXRing * CS * 512 + CS * 64; }
+__host__ __device__ constexpr size_t xbuf_tile_words(int CS, int T = 1)
+{
+    return ((size_t)kXRing * CS * 512 + CS * 64) * T;
+}
 
 __host__ __device__ constexpr int mfma1_lag(int CS) { return CS == 1 ? 3 : 5; }
 
-template <int KT>
+template <int KT, int T = 1>
 constexpr int ring1_pairs()
 {
     // X operand pairs in flight per matrix wave (must divide 4 KT); the deep tiles keep fewer so
@@ -84,7 +87,8 @@ constexpr int ring1_pairs()
     // (KT <= 4 runs chain-bound with one workgroup per tile: a deeper ring only delays the
     // helper's loads; KT = 5, 6 are bound by the operand fetch, where 12 pairs in flight per wave
     // took the n = 1000 shard from 10.9 to 10.5 ms)
-    constexpr int cap = (KT > 14 || KT <= 4) ? 6 : 12;
+    // (T = 2 keeps 16 KT residual registers: the ring shrinks as the tile deepens)
+    constexpr int cap = (T == 2) ? (KT <= 4 ? 12 : (KT <= 6 ? 8 : 6)) : ((KT > 14 || KT <= 4) ? 6 : 12);
 #endif
     int best = 1;
     for (int r = 1; r <= cap; ++r)
@@ -128,28 +132,33 @@ __device__ unsigned long long g_mfma1_stamps[4096 * 4 * 8];
 #define M1STAMP_FLUSH(role) do { } while (0)
 #endif
 
-template <int KT, int CS>
+template <int KT, int CS, int T = 1>
 __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 {
+    static_assert(T == 1 || T == 2, "one or two tiles of 16 responses per cluster");
+    static_assert(T == 1 || CS > 1, "two tiles on ONE workgroup is mfma_sweep_kernel<2, KT>");
     constexpr int L = mfma1_lag(CS);
     constexpr int MW = 6;
-    constexpr int NOP = 8 * KT, NPAIR = NOP / 2, NR2 = ring1_pairs<KT>();
+    constexpr int NOP = 8 * KT, NPAIR = NOP / 2, NR2 = ring1_pairs<KT, T>();
+    constexpr int TW = 16 * T;          // responses of a cluster = row length of the [t][k] LDS arrays
+    constexpr int TB = 256 * T;         // doubles of one 16 x 16 T block of them
     static_assert(NPAIR % NR2 == 0, "ring must divide the iteration stream");
     constexpr int DR = 8;       // delta ring, blocks (power of two, >= L)
     constexpr int CHAIN_W = 3, HELP_W = 7;
 
-    __shared__ __align__(16) double part[2 * MW * 256];  // partial G per matrix wave   [par][m][g][lane]
-    __shared__ __align__(16) double gfin[256];           // reduced G of the next chain block, D layout
-    __shared__ __align__(16) double gx[2 * 256];         // chain starting values       [par][t][r]
-    __shared__ __align__(16) double dl[DR * 256];        // deltas                      [blk & 7][t][r]
-    __shared__ __align__(16) double mg[2 * 2 * 256];     // mu, gamma of a chain block  [par][2][t][r]
-    __shared__ __align__(16) double bol[2 * 256];        // beta_old                    [par][t][r]
+    // (k = response within the cluster, 0 .. 16 T - 1 = 16 tau + r; "D layout" = [tau][g][lane])
+    __shared__ __align__(16) double part[2 * MW * TB];   // partial G per matrix wave   [par][m][tau][g][lane]
+    __shared__ __align__(16) double gfin[TB];            // reduced G of the next chain block, D layout
+    __shared__ __align__(16) double gx[2 * TB];          // chain starting values       [par][t][k]
+    __shared__ __align__(16) double dl[DR * TB];         // deltas                      [blk & 7][t][k]
+    __shared__ __align__(16) double mg[2 * 2 * TB];      // mu, gamma of a chain block  [par][2][t][k]
+    __shared__ __align__(16) double bol[2 * TB];         // beta_old                    [par][t][k]
     __shared__ __align__(16) double gram[2 * 256];       // Gram columns of a chain block [par][t][t2]
     __shared__ __align__(16) double scl[2 * 32];         // lod, xtx of its steps       [par][t][2]
     // CS > 1: A operands of the cross-block corrections of a block, staged by the helper [par][lag][lane][4]
     __shared__ __align__(16) double axl[(CS > 1) ? 2 * (L - 1) * 256 : 2];
     // CS > 1: corrections of the lags 2 .. L-1 (matrix waves 1 .. L-2), D layout, and their flags
-    __shared__ __align__(16) double cx[(CS > 1) ? (L - 2) * 256 : 2];
+    __shared__ __align__(16) double cx[(CS > 1) ? (L - 2) * TB : 2];
     __shared__ int cxf[4];
     __shared__ int jl[8 * 16];  // covariate of the steps of the blocks around the chain [blk & 7][t]
     __shared__ int prog;        // steps the chain has completed
@@ -173,13 +182,13 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     const int c_mem = (bi >> 3) % CS;
     if (g_cl >= P.ntiles || *P.err != 0) return;
     if (CS > 1 && c_mem == P.drop_member) return;
-    const int k0 = P.k_begin + 16 * g_cl;
+    const int k0 = P.k_begin + TW * g_cl;
     const int kend = P.k_end;
     const size_t pd = (size_t)P.p * d;
 
-    for (int e = tid; e < DR * 256; e += 512) dl[e] = 0.0;
-    for (int e = tid; e < 512; e += 512) { gx[e] = 0.0; bol[e] = 0.0; }
-    for (int e = tid; e < 1024; e += 512) mg[e] = 0.0;
+    for (int e = tid; e < DR * TB; e += 512) dl[e] = 0.0;
+    for (int e = tid; e < 2 * TB; e += 512) { gx[e] = 0.0; bol[e] = 0.0; }
+    for (int e = tid; e < 4 * TB; e += 512) mg[e] = 0.0;
     for (int e = tid; e < 512; e += 512) gram[e] = 0.0;
     if (tid < 64) scl[tid] = 0.0;
     if (tid < 128) jl[tid] = 0;
@@ -197,16 +206,17 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         const int m = (w > CHAIN_W) ? w - 1 : w;
         const int row0 = ((c_mem * MW + m) * KT) * 16;
 
-        d4 rv[KT];
-        {
-            const int k = k0 + r;
+        d4 rv[T][KT];
+#pragma unroll
+        for (int tau = 0; tau < T; ++tau) {
+            const int k = k0 + 16 * tau + r;
             const double* Rk = P.R + (size_t)(k < kend ? k : 0) * n;
 #pragma unroll
             for (int i = 0; i < KT; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int row = row0 + 16 * i + 4 * g + q;
-                    rv[i][g] = (k < kend && row < n) ? Rk[row] : 0.0;
+                    rv[tau][i][g] = (k < kend && row < n) ? Rk[row] : 0.0;
                 }
         }
         const double2* xp = reinterpret_cast<const double2*>(P.XS) +
@@ -227,11 +237,13 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 if (dd_ != 0 && it >= dd_) break;
             }
             M1STAMP(0);
-            double bop[4];
+            double bop[4][T];
             {
-                const double* dp = dl + ((it - L) & (DR - 1)) * 256 + q * 16 + r;
+                const double* dp = dl + ((it - L) & (DR - 1)) * TB + q * TW + r;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) bop[c] = dp[64 * c];
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int tau = 0; tau < T; ++tau) bop[c][tau] = dp[4 * TW * c + 16 * tau];
             }
             // Cross-block corrections of block bx, the one the chain runs in the NEXT iteration:
             //   gx = reduced G (helper) + sum_l (X_bx' X_{bx-l}) d_{bx-l},  l = 1 .. L-1.
@@ -245,8 +257,14 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             double2 axr[(CS > 1) ? 1 : L - 1][2];
             // clusters: this wave's lag (m + 1, for m = 1 .. L-2) of the cross-block corrections
             const bool do_corr = (CS > 1) && bx_ok && m >= 1 && m <= L - 2;
-            double cdl[4] = {0.0, 0.0, 0.0, 0.0};
-            d4 ccx = d4{0.0, 0.0, 0.0, 0.0};
+            double cdl[4][T];
+            d4 ccx[T];
+#pragma unroll
+            for (int tau = 0; tau < T; ++tau) {
+                ccx[tau] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cdl[c][tau] = 0.0;
+            }
             if constexpr (CS > 1) {
                 // (requests only; the MFMAs and the result go into the operand stream below, a
                 // quarter and a half of the way through, so that neither the LDS latency nor the
@@ -256,9 +274,11 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                         reinterpret_cast<const double2*>(axl + ((bx & 1) * (L - 1) + m) * 256) + 2 * lane;
                     axr[0][0] = ap[0];
                     axr[0][1] = ap[1];
-                    const double* dp = dl + ((bx - (m + 1)) & (DR - 1)) * 256 + q * 16 + r;
+                    const double* dp = dl + ((bx - (m + 1)) & (DR - 1)) * TB + q * TW + r;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) cdl[c] = dp[64 * c];
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int tau = 0; tau < T; ++tau) cdl[c][tau] = dp[4 * TW * c + 16 * tau];
                 }
             } else if (xw) {  // used at the end of this iteration only
 #pragma unroll
@@ -269,7 +289,14 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     axr[l - 1][1] = ap[1];
                 }
             }
-            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+            // dot accumulators: two per tile at T = 1 (consecutive MFMAs never share registers);
+            // with two tiles the tiles alternate, one each is enough
+            constexpr int NACC = (T == 1) ? 2 : 1;
+            d4 acc[T][NACC];
+#pragma unroll
+            for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                for (int a2 = 0; a2 < NACC; ++a2) acc[tau][a2] = d4{0.0, 0.0, 0.0, 0.0};
             auto slot = [&](auto oc) {
                 constexpr int o = decltype(oc)::value;
                 if constexpr (CS > 1 && o == NOP / 4) {
@@ -277,14 +304,19 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                         const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
-                            ccx = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], cdl[c], ccx, 0, 0, 0);
+#pragma unroll
+                            for (int tau = 0; tau < T; ++tau)
+                                ccx[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], cdl[c][tau],
+                                                                                ccx[tau], 0, 0, 0);
                     }
                 }
                 if constexpr (CS > 1 && o == NOP / 2) {
                     if (do_corr) {
-                        double* co = cx + (m - 1) * 256 + lane;
+                        double* co = cx + (m - 1) * TB + lane;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) co[64 * g] = ccx[g];
+                        for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) co[256 * tau + 64 * g] = ccx[tau][g];
                         lds_publish(&cxf[m - 1], it);
                     }
                 }
@@ -296,20 +328,35 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 }
                 if constexpr (o < 4 * KT) {  // R += X_{it-L} d_{it-L}
                     constexpr int i = op_tile(o, KT), c = op_sub(o, KT);
-                    rv[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[c], rv[i], 0, 0, 0);
+                    sfor<T>([&](auto tc) {
+                        constexpr int tau = decltype(tc)::value;
+                        rv[tau][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[c][tau], rv[tau][i],
+                                                                          0, 0, 0);
+                    });
                 } else {                     // partial G_it = X_it' R over this wave's rows
                     constexpr int i = op_tile(o - 4 * KT, KT), g = op_sub(o - 4 * KT, KT);
-                    acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rv[i][g], acc[i & 1], 0, 0, 0);
+                    sfor<T>([&](auto tc) {
+                        constexpr int tau = decltype(tc)::value;
+                        constexpr int a2 = (NACC == 2) ? (i & 1) : 0;
+                        acc[tau][a2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rv[tau][i][g],
+                                                                            acc[tau][a2], 0, 0, 0);
+                    });
                 }
             };
             sfor<NOP>(slot);
             M1STAMP(1);
             {
-                double* pb = part + (par * MW + m) * 256 + lane;
+                double* pb = part + (par * MW + m) * TB + lane;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pb[g * 64] = acc[0][g] + acc[1][g];
+                for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        double v = acc[tau][0][g];
+                        if constexpr (NACC == 2) v += acc[tau][1][g];
+                        pb[256 * tau + g * 64] = v;
+                    }
             }
-            if (xw) {
+            if constexpr (CS == 1) if (xw) {   // (T == 1 here: strides of 256 / 16)
                 d4 xc;
                 const double* dp = dl + ((bx - 1) & (DR - 1)) * 256 + q * 16 + r;
                 const double axv[4] = {axr[0][0].x, axr[0][0].y, axr[0][1].x, axr[0][1].y};
@@ -380,8 +427,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         asm volatile("" : "+v"(lane_e));
         asm volatile("" : "+s"(n_e), "+s"(d_e));
         const int q_e = lane_e >> 4, r_e = lane_e & 15;
-        {
-            const int k = k0 + r_e;
+#pragma unroll
+        for (int tau = 0; tau < T; ++tau) {
+            const int k = k0 + 16 * tau + r_e;
             double* Rk = P.R + (size_t)(k < d_e ? k : 0) * n_e;
             double a0 = 0.0;
 #pragma unroll
@@ -389,17 +437,17 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int row = row0 + 16 * i + 4 * g + q_e;
-                    const double v = rv[i][g];
+                    const double v = rv[tau][i][g];
                     if (alive && k < d_e && row < n_e) Rk[row] = v;
                     a0 = fma(v, v, a0);
                 }
-            part[m * 64 + lane] = a0;
+            part[(m * T + tau) * 64 + lane] = a0;
         }
         __syncthreads();  // E2
     } else if (w == CHAIN_W) {
         // =========================== chain role ===========================================
         const int kc = k0 + lane;
-        const bool cvalid = (lane < 16) && (kc < kend);
+        const bool cvalid = (lane < TW) && (kc < kend);
         double c_scale = 0.0, c_hinv = 0.0, c_cst = 0.0;
         if (cvalid) {
             c_scale = P.scale[kc];
@@ -416,11 +464,11 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             }
             M1STAMP(0);
             const int b = it - L + 1;  // block whose chain runs now
-            if (b >= 0 && b < P.nblk && lane < 16) {
-                const double* gx_l = gx + (b & 1) * 256 + lane;
-                const double* bo_l = bol + (b & 1) * 256 + lane;
-                double* dl_w = dl + (b & (DR - 1)) * 256 + lane;
-                double* mg_w = mg + (b & 1) * 512 + lane;
+            if (b >= 0 && b < P.nblk && lane < TW) {
+                const double* gx_l = gx + (b & 1) * TB + lane;
+                const double* bo_l = bol + (b & 1) * TB + lane;
+                double* dl_w = dl + (b & (DR - 1)) * TB + lane;
+                double* mg_w = mg + (b & 1) * 2 * TB + lane;
                 const double* sc_b = scl + (b & 1) * 32;      // wave-uniform addresses: broadcast reads
                 const double* cg_b = gram + (b & 1) * 256;
 
@@ -479,9 +527,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                             gc[t2] = g2.x;
                             gc[t2 + 1] = g2.y;
                         });
-                        bo_n = bo_l[(t + 1) * 16];
+                        bo_n = bo_l[(t + 1) * TW];
                         sc_n = *reinterpret_cast<const double2*>(sc_b + 2 * (t + 1));
-                        gx_n = gx_l[(t + 1) * 16];
+                        gx_n = gx_l[(t + 1) * TW];
                     }
                     LOCUS_FENCE();
                     const double a = fma(-cA, dd, cB);                         // coreLoop.cpp:42-46
@@ -494,9 +542,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     LOCUS_FENCE();
                     const double kf = __builtin_rint(x * 1.4426950408889634074);
                     if constexpr (t > 0) {
-                        dl_w[(t - 1) * 16] = delta;
-                        mg_w[(t - 1) * 16] = m_p;
-                        mg_w[256 + (t - 1) * 16] = gam_p;
+                        dl_w[(t - 1) * TW] = delta;
+                        mg_w[(t - 1) * TW] = m_p;
+                        mg_w[TB + (t - 1) * TW] = gam_p;
                         if constexpr (CS == 1 && (t & 3) == 0) lds_publish(&prog, 16 * b + t);
                     }
                     LOCUS_FENCE();
@@ -571,9 +619,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #undef LOCUS_FENCE
                 {
                     const double delta = fma(-m_p, gam_p, bo_p);
-                    dl_w[15 * 16] = delta;
-                    mg_w[15 * 16] = m_p;
-                    mg_w[256 + 15 * 16] = gam_p;
+                    dl_w[15 * TW] = delta;
+                    mg_w[15 * TW] = m_p;
+                    mg_w[TB + 15 * TW] = gam_p;
                     if constexpr (CS == 1) lds_publish(&prog, 16 * b + 16);
                 }
             }
@@ -596,16 +644,23 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     const double2* ap =
                         reinterpret_cast<const double2*>(axl + ((bx & 1) * (L - 1)) * 256) + 2 * lane;
                     const double2 a01 = ap[0], a23 = ap[1];
-                    const double* dp = dl + ((bx - 1) & (DR - 1)) * 256 + q * 16 + r;
-                    double b4[4], gq[4], cq[L - 2][4];
+                    const double* dp = dl + ((bx - 1) & (DR - 1)) * TB + q * TW + r;
+                    double b4[4][T], gq[T][4], cq[L - 2][T][4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) b4[c] = dp[64 * c];
+                    for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gq[g] = gfin[g * 64 + lane];
+                        for (int tau = 0; tau < T; ++tau) b4[c][tau] = dp[4 * TW * c + 16 * tau];
+#pragma unroll
+                    for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) gq[tau][g] = gfin[256 * tau + g * 64 + lane];
 #pragma unroll
                     for (int l = 2; l < L; ++l)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) cq[l - 2][g] = cx[(l - 2) * 256 + g * 64 + lane];
+                        for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                cq[l - 2][tau][g] = cx[(l - 2) * TB + 256 * tau + g * 64 + lane];
                     asm volatile("" ::: "memory");
                     bool ok = fl[0] >= it;
 #pragma unroll
@@ -619,24 +674,39 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                                 __builtin_amdgcn_s_sleep(1);
                         asm volatile("" ::: "memory");
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) gq[g] = gfin[g * 64 + lane];
+                        for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) gq[tau][g] = gfin[256 * tau + g * 64 + lane];
 #pragma unroll
                         for (int l = 2; l < L; ++l)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) cq[l - 2][g] = cx[(l - 2) * 256 + g * 64 + lane];
+                            for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+                                    cq[l - 2][tau][g] = cx[(l - 2) * TB + 256 * tau + g * 64 + lane];
                     }
-                    d4 xc = d4{gq[0], gq[1], gq[2], gq[3]};
+                    d4 xc[T];
 #pragma unroll
-                    for (int l = 2; l < L; ++l)   // fixed order: identical sums in every member
+                    for (int tau = 0; tau < T; ++tau) {
+                        xc[tau] = d4{gq[tau][0], gq[tau][1], gq[tau][2], gq[tau][3]};
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) xc[g] += cq[l - 2][g];
+                        for (int l = 2; l < L; ++l)   // fixed order: identical sums in every member
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) xc[tau][g] += cq[l - 2][tau][g];
+                    }
                     const double axv[4] = {a01.x, a01.y, a23.x, a23.y};
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        xc = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], b4[c], xc, 0, 0, 0);
-                    double* go = gx + (bx & 1) * 256 + q * 16 + r;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) go[64 * g] = xc[g];
+                        for (int tau = 0; tau < T; ++tau)
+                            xc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], b4[c][tau], xc[tau],
+                                                                           0, 0, 0);
+                    // D layout (t = 4 g + q, response 16 tau + r) -> gx[t][k]
+                    double* go = gx + (bx & 1) * TB + q * TW + r;
+#pragma unroll
+                    for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) go[4 * TW * g + 16 * tau] = xc[tau][g];
                 }
             }
             M1STAMP(3);
@@ -654,24 +724,33 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         // 10.9 -> 9.84 ms at n = 1000, d_loc = 1250.  CS = 1, 2 are bound elsewhere and lose
         // when the chain is delayed (n = 200, CS = 1: 3.31 -> 3.6 ms), so they keep the default.
         if constexpr (CS == 3) __builtin_amdgcn_s_setprio(2);
-        const int kh = k0 + r;
-        const bool kvalid = kh < kend;
+        // lane (q, r) serves response 16 tau + r of the cluster, tau = 0 .. T-1
+        int kh[T];
+        bool kvalid[T];
+        double c_s2[T], acc_g[T], acc_m2[T], acc_b2[T];
+#pragma unroll
+        for (int tau = 0; tau < T; ++tau) {
+            kh[tau] = k0 + 16 * tau + r;
+            kvalid[tau] = kh[tau] < kend;
+            c_s2[tau] = kvalid[tau] ? P.s2k[kh[tau]] : 0.0;
+            acc_g[tau] = acc_m2[tau] = acc_b2[tau] = 0.0;
+        }
         const bool storer = (c_mem == 0);
-        double c_s2 = kvalid ? P.s2k[kh] : 0.0;
-        double acc_g = 0.0, acc_m2 = 0.0, acc_b2 = 0.0;
         unsigned long long* xb_tile = nullptr;
         int* xf_tile = nullptr;
         if constexpr (CS > 1) {
-            xb_tile = P.xbuf + (size_t)g_cl * xbuf_tile_words(CS);
+            xb_tile = P.xbuf + (size_t)g_cl * xbuf_tile_words(CS, T);
             xf_tile = P.xflag + (size_t)g_cl * CS * 32;
         }
+        constexpr int NGV = (CS > 1) ? CS * 8 * T : 1;   // granules per lane and block
 
         // CS > 1: the members' partial tiles of the block whose reduced G is due in the NEXT
         // iteration, as granules {half a double, tag}: fetched one iteration ahead, validated (and
         // in the rare case of a late partner re-fetched) when they are due
-        unsigned long long gv[(CS > 1) ? CS * 8 : 1];
+        // (index (cm * T + tau) * 8 + e: member cm, tile tau, granule e of the lane)
+        unsigned long long gv[NGV];
 #pragma unroll
-        for (int e = 0; e < ((CS > 1) ? CS * 8 : 1); ++e) gv[e] = 0ull;
+        for (int e = 0; e < NGV; ++e) gv[e] = 0ull;
 
         for (int it = 0; it < nit; ++it) {
             __syncthreads();  // B1
@@ -683,24 +762,32 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             M1STAMP(0);
             const int bn_blk = it - L + 2;   // block the chain runs in the next iteration
             const int bs = it - L;           // block the chain finished in the last iteration
-            double pg[4] = {0.0, 0.0, 0.0, 0.0};
+            double pg[T][4];
+#pragma unroll
+            for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pg[tau][g] = 0.0;
             // ---- reduced G of block bn_blk ---------------------------------------------------------
             if constexpr (CS == 1) {
-                if (it >= 1) {
+                if (it >= 1) {   // (T == 1)
                     const double* pp = part + (((it - 1) & 1) * MW) * 256 + lane;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const double* p2 = pp + g * 64;
-                        pg[g] = ((p2[0] + p2[256]) + (p2[512] + p2[768])) + (p2[1024] + p2[1280]);
-                        gfin[g * 64 + lane] = pg[g];
+                        pg[0][g] = ((p2[0] + p2[256]) + (p2[512] + p2[768])) + (p2[1024] + p2[1280]);
+                        gfin[g * 64 + lane] = pg[0][g];
                     }
                 }
             } else {
-                double sg[4] = {0.0, 0.0, 0.0, 0.0};
+                double sg[T][4];
+#pragma unroll
+                for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) sg[tau][g] = 0.0;
                 if (bn_blk >= 0 && bn_blk < P.nblk) {
                     const unsigned tag = (unsigned)bn_blk + 1u;
                     const unsigned long long* gsrc =
-                        xb_tile + (size_t)(bn_blk % kXRing) * CS * 512 + lane;
+                        xb_tile + (size_t)(bn_blk % kXRing) * CS * T * 512 + lane;
                     // The granules were fetched one iteration ago and the wait of that iteration's
                     // hand-over covered them: the check below must not wait for anything.  (Written
                     // as one loop -- check, break, sleep, refetch -- the compiler put a vmcnt(0) in
@@ -709,7 +796,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     auto tags_ok = [&]() {
                         bool ok = true;
 #pragma unroll
-                        for (int e = 0; e < CS * 8; ++e) ok = ok && ((unsigned)(gv[e] >> 32) == tag);
+                        for (int e = 0; e < NGV; ++e) ok = ok && ((unsigned)(gv[e] >> 32) == tag);
                         return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
                     };
                     if (!tags_ok()) {  // a partner is late: poll
@@ -724,13 +811,13 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                             tacc[7] += 1;  // refetches
 #endif
 #pragma unroll
-                            for (int e = 0; e < CS * 8; ++e)
+                            for (int e = 0; e < NGV; ++e)
                                 gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_AGENT);
                             // pin: the wait for these loads is issued HERE, on the slow path, and
                             // the registers leave it with nothing pending
 #pragma unroll
-                            for (int e = 0; e < CS * 8; ++e) asm volatile("" : "+v"(gv[e]));
+                            for (int e = 0; e < NGV; ++e) asm volatile("" : "+v"(gv[e]));
                             if (tags_ok()) break;
                         }
                     }
@@ -738,20 +825,29 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #pragma unroll
                     for (int cm = 0; cm < CS; ++cm)   // member order: identical sums in every member
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const unsigned long long lo = gv[cm * 8 + 2 * g] & 0xffffffffull;
-                            const unsigned long long hi = gv[cm * 8 + 2 * g + 1] << 32;
-                            sg[g] += __longlong_as_double((long long)(hi | lo));
-                        }
+                        for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int e0 = (cm * T + tau) * 8 + 2 * g;
+                                const unsigned long long lo = gv[e0] & 0xffffffffull;
+                                const unsigned long long hi = gv[e0 + 1] << 32;
+                                sg[tau][g] += __longlong_as_double((long long)(hi | lo));
+                            }
                 }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gfin[g * 64 + lane] = sg[g];
+                for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gfin[256 * tau + g * 64 + lane] = sg[tau][g];
             }
             M1STAMP(1);
             lds_publish(&gfin_ready, it);
 
             // ---- requests: everything this iteration needs from global memory, at once -----------
-            double bo_v[4] = {0.0, 0.0, 0.0, 0.0};
+            double bo_v[T][4];
+#pragma unroll
+            for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                for (int rd = 0; rd < 4; ++rd) bo_v[tau][rd] = 0.0;
             double2 gr_v[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
             double2 sc_v = make_double2(0.0, 0.0);
             int jv = 0;
@@ -779,31 +875,39 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 gr_v[1] = gsrc[1];
                 if (lane < 16)
                     sc_v = reinterpret_cast<const double2*>(P.sc2 + (size_t)32 * bn_blk)[lane];
-                if (kvalid) {
+                {
                     const int* jp = jl + (bn_blk & 7) * 16 + q;
 #pragma unroll
                     for (int rd = 0; rd < 4; ++rd)
-                        if (16 * bn_blk + 4 * rd + q < P.nsteps)
-                            bo_v[rd] = P.state[2 * pd + (size_t)jp[4 * rd] * d + kh];
+                        if (16 * bn_blk + 4 * rd + q < P.nsteps) {
+                            const double* row = P.state + 2 * pd + (size_t)jp[4 * rd] * d;
+#pragma unroll
+                            for (int tau = 0; tau < T; ++tau)
+                                if (kvalid[tau]) bo_v[tau][rd] = row[kh[tau]];
+                        }
                 }
             }
             if constexpr (CS > 1) {
                 // ---- granules of the block due next iteration (published a whole iteration ago) ---
                 const int bg = bn_blk + 1;
                 if (bg >= 0 && bg < P.nblk) {
-                    const unsigned long long* gsrc = xb_tile + (size_t)(bg % kXRing) * CS * 512 + lane;
+                    const unsigned long long* gsrc =
+                        xb_tile + (size_t)(bg % kXRing) * CS * T * 512 + lane;
 #pragma unroll
-                    for (int e = 0; e < CS * 8; ++e)
+                    for (int e = 0; e < NGV; ++e)
                         gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 // ---- this member's partial tile of block it - 1: reduce (published below) --------
                 if (it >= 1 && it - 1 < P.nblk) {
-                    const double* pp = part + (((it - 1) & 1) * MW) * 256 + lane;
+                    const double* pp = part + (((it - 1) & 1) * MW) * TB + lane;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const double* p2 = pp + g * 64;
-                        pg[g] = ((p2[0] + p2[256]) + (p2[512] + p2[768])) + (p2[1024] + p2[1280]);
-                    }
+                    for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const double* p2 = pp + 256 * tau + g * 64;
+                            pg[tau][g] = ((p2[0] + p2[TB]) + (p2[2 * TB] + p2[3 * TB])) +
+                                         (p2[4 * TB] + p2[5 * TB]);
+                        }
                 }
             }
             // everything the chain and the memory system wait for is out: back behind the chain
@@ -815,9 +919,11 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             // for these loads behind the stores would also wait for the stores' write-through).
             __builtin_amdgcn_sched_barrier(0);
             if (bn_blk >= 0 && bn_blk < P.nblk) {
-                double* bp = bol + (bn_blk & 1) * 256 + q * 16 + r;
+                double* bp = bol + (bn_blk & 1) * TB + q * TW + r;
 #pragma unroll
-                for (int rd = 0; rd < 4; ++rd) bp[64 * rd] = bo_v[rd];
+                for (int rd = 0; rd < 4; ++rd)
+#pragma unroll
+                    for (int tau = 0; tau < T; ++tau) bp[4 * TW * rd + 16 * tau] = bo_v[tau][rd];
                 double2* gp = reinterpret_cast<double2*>(gram + (bn_blk & 1) * 256) + 2 * lane;
                 gp[0] = gr_v[0];
                 gp[1] = gr_v[1];
@@ -835,7 +941,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 }
                 // the granules just fetched are complete as well: pin them before the stores
 #pragma unroll
-                for (int e = 0; e < CS * 8; ++e) asm volatile("" : "+v"(gv[e]));
+                for (int e = 0; e < NGV; ++e) asm volatile("" : "+v"(gv[e]));
             }
             __builtin_amdgcn_sched_barrier(0);
             M1STAMP(5);
@@ -844,34 +950,44 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 if (it >= 1 && it - 1 < P.nblk) {
                     const unsigned long long tagw = (unsigned long long)(unsigned)it << 32;  // block + 1
                     unsigned long long* slot =
-                        xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * 512 + lane;
+                        xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * T * 512 + lane;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const unsigned long long bits = (unsigned long long)__double_as_longlong(pg[g]);
-                        __hip_atomic_store(slot + 64 * (2 * g), tagw | (bits & 0xffffffffull),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(slot + 64 * (2 * g + 1), tagw | (bits >> 32),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const unsigned long long bits =
+                                (unsigned long long)__double_as_longlong(pg[tau][g]);
+                            __hip_atomic_store(slot + 512 * tau + 64 * (2 * g),
+                                               tagw | (bits & 0xffffffffull), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(slot + 512 * tau + 64 * (2 * g + 1), tagw | (bits >> 32),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                 }
             }
             // ---- results of the block the chain finished last iteration -----------------------
-            if (storer && bs >= 0 && bs < P.nblk && kvalid && (CS == 1 || lds_peek(&dead) == 0)) {
-                const double* mp = mg + (bs & 1) * 512 + q * 16 + r;
+            if (storer && bs >= 0 && bs < P.nblk && (CS == 1 || lds_peek(&dead) == 0)) {
+                const double* mp = mg + (bs & 1) * 2 * TB + q * TW + r;
                 const int* jp = jl + (bs & 7) * 16 + q;
 #pragma unroll
                 for (int rd = 0; rd < 4; ++rd) {
                     const int s = 16 * bs + 4 * rd + q;
                     if (s < P.nsteps) {
-                        const double mv = mp[64 * rd], gv2 = mp[256 + 64 * rd];
-                        const double bv = mv * gv2;
-                        double* o = P.state + (size_t)jp[4 * rd] * d + kh;
-                        o[0] = gv2;
-                        o[pd] = mv;
-                        o[2 * pd] = bv;
-                        acc_g += gv2;
-                        acc_m2 = fma(gv2, fma(mv, mv, c_s2), acc_m2);
-                        acc_b2 = fma(bv, bv, acc_b2);
+                        double* orow = P.state + (size_t)jp[4 * rd] * d;
+#pragma unroll
+                        for (int tau = 0; tau < T; ++tau)
+                            if (kvalid[tau]) {
+                                const double mv = mp[4 * TW * rd + 16 * tau];
+                                const double gv2 = mp[TB + 4 * TW * rd + 16 * tau];
+                                const double bv = mv * gv2;
+                                double* o = orow + kh[tau];
+                                o[0] = gv2;
+                                o[pd] = mv;
+                                o[2 * pd] = bv;
+                                acc_g[tau] += gv2;
+                                acc_m2[tau] = fma(gv2, fma(mv, mv, c_s2[tau]), acc_m2[tau]);
+                                acc_b2[tau] = fma(bv, bv, acc_b2[tau]);
+                            }
                     }
                 }
             }
@@ -881,29 +997,41 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         __syncthreads();  // E1
         const bool alive = (CS == 1) || lds_peek(&dead) == 0;
         // column statistics: sum the four step classes of a response through LDS (gfin is free)
-        gfin[lane] = acc_g;
-        gfin[64 + lane] = acc_m2;
-        gfin[128 + lane] = acc_b2;
-        __syncthreads();  // E2: the matrix waves' sums of squares are in `part`
-        double rss = 0.0;
-        if (lane < 16) {
 #pragma unroll
-            for (int ss = 0; ss < MW; ++ss) {
-                const double* pp = part + ss * 64 + lane;
-                rss += (pp[0] + pp[16]) + (pp[32] + pp[48]);
+        for (int tau = 0; tau < T; ++tau) {
+            gfin[256 * tau + lane] = acc_g[tau];
+            gfin[256 * tau + 64 + lane] = acc_m2[tau];
+            gfin[256 * tau + 128 + lane] = acc_b2[tau];
+        }
+        __syncthreads();  // E2: the matrix waves' sums of squares are in `part`
+        double rss[T];
+#pragma unroll
+        for (int tau = 0; tau < T; ++tau) {
+            rss[tau] = 0.0;
+            if (lane < 16) {
+#pragma unroll
+                for (int ss = 0; ss < MW; ++ss) {
+                    const double* pp = part + (ss * T + tau) * 64 + lane;
+                    rss[tau] += (pp[0] + pp[16]) + (pp[32] + pp[48]);
+                }
             }
         }
         if (CS > 1 && alive) {
             // sum of squares over the members' row slices, added in member order by member 0
-            double* rs_base = reinterpret_cast<double*>(xb_tile + (size_t)kXRing * CS * 512);
-            if (lane < 16)
-                __hip_atomic_store(rs_base + c_mem * 64 + lane, rss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double* rs_base = reinterpret_cast<double*>(xb_tile + (size_t)kXRing * CS * T * 512);
+            if (lane < 16) {
+#pragma unroll
+                for (int tau = 0; tau < T; ++tau)
+                    __hip_atomic_store(rs_base + (c_mem * T + tau) * 64 + lane, rss[tau], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_store(xf_tile + c_mem * 32, nit + 1, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             if (storer) {
-                rss = 0.0;
+#pragma unroll
+                for (int tau = 0; tau < T; ++tau) rss[tau] = 0.0;
 #pragma unroll
                 for (int cm = 0; cm < CS; ++cm) {
                     int spin = 0;
@@ -915,18 +1043,26 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                             break;
                         }
                     }
-                    if (lane < 16)
-                        rss += __hip_atomic_load(rs_base + cm * 64 + lane, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane < 16) {
+#pragma unroll
+                        for (int tau = 0; tau < T; ++tau)
+                            rss[tau] += __hip_atomic_load(rs_base + (cm * T + tau) * 64 + lane,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         }
-        if (alive && P.st != nullptr && storer && lane < 16 && kvalid) {
-            const double* sp = gfin + lane;
-            P.st[kh] = (sp[0] + sp[16]) + (sp[32] + sp[48]);
-            P.st[(size_t)d + kh] = (sp[64] + sp[80]) + (sp[96] + sp[112]);
-            P.st[2 * (size_t)d + kh] = (sp[128] + sp[144]) + (sp[160] + sp[176]);
-            P.st[3 * (size_t)d + kh] = rss;
+        if (alive && P.st != nullptr && storer && lane < 16) {
+#pragma unroll
+            for (int tau = 0; tau < T; ++tau)
+                if (kvalid[tau]) {
+                    const double* sp = gfin + 256 * tau + lane;
+                    const int k = kh[tau];
+                    P.st[k] = (sp[0] + sp[16]) + (sp[32] + sp[48]);
+                    P.st[(size_t)d + k] = (sp[64] + sp[80]) + (sp[96] + sp[112]);
+                    P.st[2 * (size_t)d + k] = (sp[128] + sp[144]) + (sp[160] + sp[176]);
+                    P.st[3 * (size_t)d + k] = rss[tau];
+                }
         }
     }
 }

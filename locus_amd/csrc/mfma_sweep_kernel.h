@@ -89,6 +89,8 @@ __host__ __device__ constexpr int op_index(int i, int c, int KT)
 #define LOCUS_MFMA1_KTS_C2(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
 // ... over 3 workgroups (18 matrix waves): KT = 7 covers the n <= 2016 of the matrix-core sweep
 #define LOCUS_MFMA1_KTS_C3(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+// two tiles (32 responses) per cluster of 2, 3 or 4 workgroups: 16 KT residual registers per wave
+#define LOCUS_MFMA1_KTS_T2(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 
 struct MfmaSweepParams {
     int n, p, d;

@@ -101,8 +101,8 @@ def test_bad_permutation_rejected(hip):
     assert np.array_equal(before, inp["gam_vb"])
 
 
-@pytest.mark.parametrize("cs,drop", [(2, 1), (3, 2), (2, 0)])
-def test_cluster_timeout_is_a_named_failure(oracle, hip, cs, drop, monkeypatch):
+@pytest.mark.parametrize("t,cs,drop", [(1, 2, 1), (1, 3, 2), (1, 2, 0), (2, 4, 3), (2, 2, 0)])
+def test_cluster_timeout_is_a_named_failure(oracle, hip, t, cs, drop, monkeypatch):
     """A row-split cluster whose partner workgroup never runs (LOCUS_HIP_TEST_DROP_MEMBER makes
     that member of every cluster return at entry, as if it had not been dispatched): the other
     members give up after their bounded wait, the call fails with LOCUS_HIP_ETIMEOUT and its own
@@ -112,7 +112,7 @@ def test_cluster_timeout_is_a_named_failure(oracle, hip, cs, drop, monkeypatch):
     from locus_amd._lib import LocusHipError
     inp = inputs_for("identity", 300, 53, 39, seed=4)
     before = {k: np.array(inp[k], copy=True) for k in ("gam_vb", "beta_vb", "mat_x_m1", "mu_beta_vb")}
-    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-1,1,{cs},0")
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-1,{t},{cs},0")
     monkeypatch.setenv("LOCUS_HIP_TEST_DROP_MEMBER", str(drop))
     with pytest.raises(LocusHipError) as ei:
         call_variant(hip, "identity", inp)
@@ -123,7 +123,7 @@ def test_cluster_timeout_is_a_named_failure(oracle, hip, cs, drop, monkeypatch):
     monkeypatch.delenv("LOCUS_HIP_TEST_DROP_MEMBER")
     ref = call_variant(oracle, "identity", inp)
     got = call_variant(hip, "identity", inp)
-    assert_parity(got, ref, what=f"identity after a cluster time-out, CS = {cs}")
+    assert_parity(got, ref, what=f"identity after a cluster time-out, T = {t}, CS = {cs}")
 
 
 def test_cluster_timeout_resident_state(hip, monkeypatch):
@@ -195,13 +195,20 @@ def test_two_sweeps_in_a_row_deterministic(hip):
 MFMA_GEOMS = ([f"-1,1,1,{kt}" for kt in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 21)]
               + [f"-1,1,2,{kt}" for kt in range(1, 12)]          # rows cut over 2 workgroups
               + [f"-1,1,3,{kt}" for kt in range(1, 8)] + ["-1,1,3,0"]  # ... over 3
-              + [f"-1,2,8,{kt}" for kt in range(1, 12)] + ["-1,1,1,0", "-1,1,2,0", "-1,1,0,0", "-1,2,8,0"])
+              + [f"-1,2,8,{kt}" for kt in range(1, 12)] + ["-1,1,1,0", "-1,1,2,0", "-1,1,0,0", "-1,2,8,0"]
+              # two tiles (32 responses) per cluster of 2, 3, 4 workgroups
+              # (16-row tiles per wave up to what covers the kernel's n <= 2016)
+              + [f"-1,2,{cs},{kt}" for cs, top in ((2, 8), (3, 7), (4, 6)) for kt in range(1, top + 1)]
+              + ["-1,2,2,0", "-1,2,3,0", "-1,2,4,0"])
 
 
 @pytest.mark.parametrize("geom", MFMA_GEOMS)
 def test_mfma_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
     _, t, cs, kt = map(int, geom.split(","))
-    waves = 7 if t == 2 else (6 * cs if cs in (2, 3) else 6)  # matrix waves over the rows
+    if t == 2:
+        waves = 6 * cs if cs in (2, 3, 4) else 7   # clusters of cs workgroups / one workgroup
+    else:
+        waves = 6 * cs if cs in (2, 3) else 6      # matrix waves over the rows
     n = min(waves * 16 * kt - 5, 2016) if kt else 300       # x 16-row tiles, ragged; kernel limit
     p, d = 53, 16 * t + 16 * t + 7    # 3 blocks + 5 steps; partial last workgroup / tile
     inp = inputs_for("identity", n, p, d, seed=21)
@@ -212,7 +219,8 @@ def test_mfma_sweep_geometries_identity(oracle, hip, geom, monkeypatch):
 
 
 EXTREME_CFGS = [("identity", "0,0,0,0"), ("identity", "-1,2,8,0"), ("identity", "-1,1,1,0"),
-                ("identity", "-1,1,2,0"), ("identity", "-1,1,3,0"), ("identity", "4,1,1,1"),
+                ("identity", "-1,1,2,0"), ("identity", "-1,1,3,0"), ("identity", "-1,2,3,0"),
+                ("identity", "4,1,1,1"),
                 ("logit", "0,0,0,0"), ("logit", "-3,2,0,0"), ("logit", "4,1,1,1")]
 
 
@@ -290,6 +298,20 @@ def test_mfma_three_member_clusters_variants(oracle, hip, variant, shape, monkey
     ref = call_variant(oracle, variant, inp)
     got = call_variant(hip, variant, inp)
     assert_parity(got, ref, what=f"{variant} {shape} three-member clusters")
+
+
+@pytest.mark.parametrize("cs", [2, 3, 4])
+@pytest.mark.parametrize("variant", ["identity", "z", "struct", "probit"])
+@pytest.mark.parametrize("shape", [(1000, 64, 71), (500, 33, 70), (130, 21, 3), (333, 100, 33)])
+def test_mfma_two_tile_clusters_variants(oracle, hip, variant, shape, cs, monkeypatch):
+    """Two tiles (32 responses) per cluster of 2, 3, 4 workgroups for every member of the identity
+    family: ragged rows, a ragged last cluster (one tile, or part of one), sweeps of 2 to 7 blocks."""
+    n, p, d = shape
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-1,2,{cs},0")
+    inp = inputs_for(variant, n, p, d, seed=5 * n + p + d + cs, c=0.6 if variant == "identity" else 1.0)
+    ref = call_variant(oracle, variant, inp)
+    got = call_variant(hip, variant, inp)
+    assert_parity(got, ref, what=f"{variant} {shape} two tiles per cluster of {cs}")
 
 
 @pytest.mark.parametrize("variant", ["identity", "struct"])
