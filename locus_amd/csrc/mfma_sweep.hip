@@ -490,9 +490,9 @@ static int pack_and_launch1(const SweepParams& prm, int T, int CS, int KT, int k
         const int ke = std::min(k_end, k + TW * max_tiles);
         mp.k_begin = k; mp.k_end = ke;
         mp.ntiles = (ke - k + TW - 1) / TW;
-        if (CS > 1) {  // a granule / flag is valid when it carries this launch's tag: start from zero
-            LOCUS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * mp.ntiles *
-                                                        xbuf_tile_words(CS, T), st));
+        if (CS > 1) {  // every exchange slot starts empty (kXEmpty), every end-of-sweep flag at zero
+            LOCUS_HIP_CHECK(hipMemsetAsync(xbuf, 0xFF, sizeof(unsigned long long) * mp.ntiles *
+                                                           xbuf_tile_words(CS, T), st));  // kXEmpty
             LOCUS_HIP_CHECK(hipMemsetAsync(xflag, 0, sizeof(int) * (size_t)mp.ntiles * CS * 32, st));
         }
         dim3 grid((unsigned)(((mp.ntiles + 7) / 8) * 8 * CS));
@@ -538,24 +538,25 @@ static int choose_cs(int n, int tiles)
 // ---------------------------------------------------------------------------
 // Launch plan.  A launch's duration does not depend on how many of its workgroups are busy --
 // every cluster walks the same p covariates -- but on what bounds one block of 16 steps in its
-// geometry (cycles, measured at n = 1000 on MI355X and extended in KT, the 16-row tiles per matrix
-// wave):
-//   matrix work   two matrix waves per SIMD x 8 KT T MFMAs of 64 cycles        = 1024 KT T
-//   operand fetch six waves x 8 KT operands of 512 B through the CU's L1 at ~20 B/clk = 1229 KT
-//   chain         16 dependent updates, ~5600 alone, ~6500 with the cluster hand-over
-//   A (mfma_sweep_kernel<2, KT>: 32 responses on ONE CU, 7 matrix waves, the chain shares a SIMD
-//      with one of them): 2048 KT + 2300
-// Geometries: A; one tile of 16 responses on 1, 2, 3 CUs; two tiles (32 responses) on 2, 3, 4
-// CUs.  Members of a cluster must all be resident, so a cluster launch takes at most
+// geometry.  Microseconds per block, measured on MI355X at n = 1000, p = 50 000 (round 3,
+// scripts/shard_sweeps.sh) and extended linearly in KT, the 16-row tiles per matrix wave:
+//   A  = mfma_sweep_kernel<2, KT>: 32 responses on ONE CU, 7 matrix waves, the chain shares a
+//        SIMD with one of them; matrix-bound: 8.58 at KT = 9                       0.953 KT
+//   one tile of 16 responses on 1, 2, 3 CUs: bound by the operand fetch of the six matrix waves
+//        through the CU's L1 (5.63 at KT = 11, 3.42 at KT = 6)                     0.54 KT
+//        or by the chain: 2.5 alone, 3.1 with the cluster hand-over (3.17 at CS = 3, KT = 4)
+//   two tiles (32 responses) on 2, 3, 4 CUs: matrix-bound (6.27 at KT = 6)         1.05 KT
+//        or by the chain and the helper sharing a SIMD with twice the hand-over: 4.36
+// Members of a cluster must all be resident, so a cluster launch takes at most
 // floor(CUs / 8 CS) 8 clusters.  The plan minimises the sum of the launch durations over all ways
-// of covering d responses (dynamic programme over units of 16 responses); every launch re-packs
-// the block operands for its row tiling (~400 cycles per block).
+// of covering d responses (dynamic programme over units of 16 responses); every launch of a new
+// geometry re-packs the block operands for its row tiling (~0.2 us per block).
 // ---------------------------------------------------------------------------
 struct LaunchType {
     int T, CS;      // CS = 0: mfma_sweep_kernel<2, KT> (one workgroup per 32 responses)
     int KT;
     int cap;        // responses one launch takes
-    double cost;    // cycles per block of 16 steps
+    double cost;    // microseconds per block of 16 steps (model above)
 };
 
 static std::vector<LaunchType> launch_types(int n)
@@ -571,9 +572,9 @@ static std::vector<LaunchType> launch_types(int n)
         int t = 0, c = 0;
         if (sscanf(e, "%d,%d", &t, &c) == 2) { only_t = t; only_cs = c; }
     }
-    const double pack = 400.0;
+    const double pack = 0.2;
     if (const int kt = mfma_kt_for(n, 2); kt > 0 && (only_t == 0 || only_t == 1))
-        v.push_back({2, 0, kt, 32 * cus, 2048.0 * kt + 2300.0 + pack});
+        v.push_back({2, 0, kt, 32 * cus, 0.953 * kt + pack});
     for (int T = 1; T <= 2; ++T)
         for (int CS = (T == 1 ? 1 : 2); CS <= (T == 1 ? 3 : 4); ++CS) {
             if (only_t != 0 && (T != only_t || CS != only_cs)) continue;
@@ -581,9 +582,9 @@ static std::vector<LaunchType> launch_types(int n)
             const int c = (CS == 1) ? cus : ccus;
             if (kt == 0 || (CS > 1 && c < 8 * CS)) continue;
             const int clusters = (CS == 1) ? c : (c / (8 * CS)) * 8;
-            const double chain = (CS == 1) ? 5600.0 : 6500.0;
-            const double work = std::max(1024.0 * kt * T, 1229.0 * kt);
-            v.push_back({T, CS, kt, 16 * T * clusters, std::max(work, chain) + 500.0 + pack});
+            const double chain = (T == 2) ? 4.36 : ((CS == 1) ? 2.5 : 3.1);
+            const double work = (T == 2) ? 1.05 * kt : 0.54 * kt;
+            v.push_back({T, CS, kt, 16 * T * clusters, std::max(work, chain) + pack});
         }
     return v;
 }

@@ -24,10 +24,11 @@
 //       finished one iteration ago to global memory and accumulates the fused column statistics.
 //
 // Row-split clusters (CS = 2, 3): the 16 responses' rows are cut over CS workgroups on CS CUs.
-// Each member projects / updates its own rows, publishes its partial G tile (2 KB per block)
-// through global memory as tagged 8-byte granules {32 bits of a double, block + 1} written and
-// read with agent-scope relaxed atomics (a granule is valid when its tag matches: no flag, no
-// fence in steady state), and EVERY member runs the same chain on the same sums (added in member
+// Each member projects / updates its own rows, publishes its partial G tile (2 KB per block and
+// tile) through global memory as 8-byte granules -- one double each, written and read with
+// agent-scope relaxed atomics; a slot that has not been written holds the sentinel ~0 (a NaN bit
+// pattern no arithmetic produces), so a granule is valid when it differs from it: no flag, no
+// fence in steady state --, and EVERY member runs the same chain on the same sums (added in member
 // order, so the chains are bit-identical and no delta ever has to travel).  The look-ahead is
 // deepened to L = 5 blocks so that a partial tile has two block times (~6 us) to arrive.  All
 // waits are bounded: a partner that does not show up raises the error word instead of hanging
@@ -59,9 +60,11 @@ struct Mfma1Params {
     double* state;        // [3][p][d]
     double* st;           // [4][d] or nullptr
     // CS > 1: exchange of the members' partial G tiles, [ntiles][kXTile] 8-byte words per cluster:
-    // kXRing slots x CS members x T x 512 granules {32 bits of a double, tag = block + 1} (zeroed by
-    // the host before every launch: a granule is valid when its tag matches), then CS x T x 64
-    // doubles for the members' sums of squares of the residual at the end of the sweep
+    // kXRing slots x CS members x T x 256 granules (one double each; the host fills the buffer
+    // with the sentinel kXEmpty before every launch, and a member that publishes block b also
+    // resets its slot of block b + kXRing / 2 -- by then every member has consumed what it held,
+    // see the helper role), then CS x T x 64 doubles for the members' sums of squares of the
+    // residual at the end of the sweep
     unsigned long long* xbuf;
     int* xflag;           // CS > 1: [ntiles][CS][32] end-of-sweep flags of the members
     int drop_member;      // test hook (LOCUS_HIP_TEST_DROP_MEMBER): this member of every cluster
@@ -69,9 +72,10 @@ struct Mfma1Params {
 };
 
 constexpr int kXRing = 16;  // exchange slots per member; >= 2 L + 1 blocks can be in flight
+constexpr unsigned long long kXEmpty = ~0ull;  // "not written yet" (hipMemsetAsync with 0xFF)
 __host__ __device__ constexpr size_t xbuf_tile_words(int CS, int T = 1)
 {
-    return ((size_t)kXRing * CS * 512 + CS * 64) * T;
+    return ((size_t)kXRing * CS * 256 + CS * 64) * T;
 }
 
 __host__ __device__ constexpr int mfma1_lag(int CS) { return CS == 1 ? 3 : 5; }
@@ -742,12 +746,12 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             xb_tile = P.xbuf + (size_t)g_cl * xbuf_tile_words(CS, T);
             xf_tile = P.xflag + (size_t)g_cl * CS * 32;
         }
-        constexpr int NGV = (CS > 1) ? CS * 8 * T : 1;   // granules per lane and block
+        constexpr int NGV = (CS > 1) ? CS * 4 * T : 1;   // granules per lane and block
 
         // CS > 1: the members' partial tiles of the block whose reduced G is due in the NEXT
-        // iteration, as granules {half a double, tag}: fetched one iteration ahead, validated (and
-        // in the rare case of a late partner re-fetched) when they are due
-        // (index (cm * T + tau) * 8 + e: member cm, tile tau, granule e of the lane)
+        // iteration, one granule per double: fetched one iteration ahead, validated (and in the
+        // rare case of a late partner re-fetched) when they are due
+        // (index (cm * T + tau) * 4 + g: member cm, tile tau, accumulator register g of the lane)
         unsigned long long gv[NGV];
 #pragma unroll
         for (int e = 0; e < NGV; ++e) gv[e] = 0ull;
@@ -785,9 +789,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) sg[tau][g] = 0.0;
                 if (bn_blk >= 0 && bn_blk < P.nblk) {
-                    const unsigned tag = (unsigned)bn_blk + 1u;
                     const unsigned long long* gsrc =
-                        xb_tile + (size_t)(bn_blk % kXRing) * CS * T * 512 + lane;
+                        xb_tile + (size_t)(bn_blk % kXRing) * CS * T * 256 + lane;
                     // The granules were fetched one iteration ago and the wait of that iteration's
                     // hand-over covered them: the check below must not wait for anything.  (Written
                     // as one loop -- check, break, sleep, refetch -- the compiler put a vmcnt(0) in
@@ -796,7 +799,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     auto tags_ok = [&]() {
                         bool ok = true;
 #pragma unroll
-                        for (int e = 0; e < NGV; ++e) ok = ok && ((unsigned)(gv[e] >> 32) == tag);
+                        for (int e = 0; e < NGV; ++e) ok = ok && (gv[e] != kXEmpty);
                         return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
                     };
                     if (!tags_ok()) {  // a partner is late: poll
@@ -827,12 +830,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #pragma unroll
                         for (int tau = 0; tau < T; ++tau)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const int e0 = (cm * T + tau) * 8 + 2 * g;
-                                const unsigned long long lo = gv[e0] & 0xffffffffull;
-                                const unsigned long long hi = gv[e0 + 1] << 32;
-                                sg[tau][g] += __longlong_as_double((long long)(hi | lo));
-                            }
+                            for (int g = 0; g < 4; ++g)
+                                sg[tau][g] += __longlong_as_double((long long)gv[(cm * T + tau) * 4 + g]);
                 }
 #pragma unroll
                 for (int tau = 0; tau < T; ++tau)
@@ -892,7 +891,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 const int bg = bn_blk + 1;
                 if (bg >= 0 && bg < P.nblk) {
                     const unsigned long long* gsrc =
-                        xb_tile + (size_t)(bg % kXRing) * CS * T * 512 + lane;
+                        xb_tile + (size_t)(bg % kXRing) * CS * T * 256 + lane;
 #pragma unroll
                     for (int e = 0; e < NGV; ++e)
                         gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -948,20 +947,28 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             if constexpr (CS > 1) {
                 // ---- publish this member's partial tile of block it - 1 ---------------------------
                 if (it >= 1 && it - 1 < P.nblk) {
-                    const unsigned long long tagw = (unsigned long long)(unsigned)it << 32;  // block + 1
+                    // Block it - 1 goes to ring slot (it - 1) % kXRing; the slot half a ring ahead,
+                    // which held block it - 1 - kXRing / 2, is reset to "empty" for block it - 1 +
+                    // kXRing / 2.  Nobody can still want the old block: this member validated block
+                    // it - L + 2 of EVERY member at the top of this iteration, so all members have
+                    // passed their iteration it - L + 3 = it - 2, and a block B is validated for
+                    // the last time in iteration B + L - 2 (here: it - 1 - 8 + 3 = it - 6).  And the
+                    // reset is visible in time: this wave waits for all its stores once per
+                    // iteration (the hand-over wait), three iterations and more before a reader
+                    // may look at the slot again.
                     unsigned long long* slot =
-                        xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * T * 512 + lane;
+                        xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * T * 256 + lane;
+                    unsigned long long* slot_rst =
+                        xb_tile + ((size_t)((it - 1 + kXRing / 2) % kXRing) * CS + c_mem) * T * 256 + lane;
 #pragma unroll
                     for (int tau = 0; tau < T; ++tau)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const unsigned long long bits =
-                                (unsigned long long)__double_as_longlong(pg[tau][g]);
-                            __hip_atomic_store(slot + 512 * tau + 64 * (2 * g),
-                                               tagw | (bits & 0xffffffffull), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(slot + 512 * tau + 64 * (2 * g + 1), tagw | (bits >> 32),
+                            __hip_atomic_store(slot + 256 * tau + 64 * g,
+                                               (unsigned long long)__double_as_longlong(pg[tau][g]),
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(slot_rst + 256 * tau + 64 * g, kXEmpty, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
                         }
                 }
             }
@@ -1018,7 +1025,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         }
         if (CS > 1 && alive) {
             // sum of squares over the members' row slices, added in member order by member 0
-            double* rs_base = reinterpret_cast<double*>(xb_tile + (size_t)kXRing * CS * T * 512);
+            double* rs_base = reinterpret_cast<double*>(xb_tile + (size_t)kXRing * CS * T * 256);
             if (lane < 16) {
 #pragma unroll
                 for (int tau = 0; tau < T; ++tau)
