@@ -13,12 +13,11 @@
 namespace locus {
 
 int launch_mfma_sweep_t2(const MfmaSweepParams&, int, dim3, dim3, size_t, hipStream_t);
-int launch_mfma_sweep1_c1(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
-int launch_mfma_sweep1_c2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
-int launch_mfma_sweep1_c3(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
-int launch_mfma_sweep1_c2t2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
-int launch_mfma_sweep1_c3t2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
-int launch_mfma_sweep1_c4t2(const Mfma1Params&, int KT, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c1(const Mfma1Params&, int KT, int odd, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c2(const Mfma1Params&, int KT, int odd, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c3(const Mfma1Params&, int KT, int odd, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c2t2(const Mfma1Params&, int KT, int odd, dim3 grid, hipStream_t);
+int launch_mfma_sweep1_c3t2(const Mfma1Params&, int KT, int odd, dim3 grid, hipStream_t);
 
 // ---------------------------------------------------------------------------
 // Block packing for mfma_sweep1_kernel (look-ahead of L blocks, NW = CS * 6 row groups).  One
@@ -32,7 +31,7 @@ __global__ void __launch_bounds__(256)
 pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ steps,
                     double* __restrict__ XS, double* __restrict__ cg, double* __restrict__ ax,
                     double* __restrict__ sc2, int* __restrict__ jidx, int ld, int KT, int nblk, int NW,
-                    int nsteps)
+                    int nsteps, int ODD)
 {
     extern __shared__ double pk_smem[];
     double (*xt)[130] = reinterpret_cast<double (*)[130]>(pk_smem);               // block b
@@ -54,8 +53,12 @@ pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ s
         sc2[(size_t)(16 * b + tid) * 2] = st.lod;
         sc2[(size_t)(16 * b + tid) * 2 + 1] = st.xtx;
     }
-    const int rows_pad = NW * 16 * KT;
-    const int NOP = 8 * KT;
+    // rows are dealt to the matrix waves in 16-row tiles: per workgroup, waves 0..2 take KT tiles
+    // each and waves 3..5 take KT - ODD (mfma_sweep1_kernel.h); the waves' operand streams follow
+    // one another, 8 operands of 64 doubles per tile and iteration
+    const int TPM = mfma1_member_tiles(KT, ODD);
+    const int ntile = (NW / 6) * TPM;
+    const int rows_pad = ntile * 16;
     const int gt = tid >> 4, gs = tid & 15;
     // Gram tiles X_b' X_{b-l}, l = 0 .. L-1, on the matrix cores: wave w contracts rows
     // 32 w .. 32 w + 31 of every 128-row chunk (8 k-steps of v_mfma_f64_16x16x4_f64 per lag),
@@ -97,19 +100,24 @@ pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ s
             const int sub = (o >> 6) & 3;
             const int gl = o >> 8;
             const int gtile = (c0 >> 4) + gl;
-            if (gtile < NW * KT) {
-                const int wv = gtile / KT, ti = gtile - wv * KT;
-                const int oi = op_index(ti, sub, KT);
+            if (gtile < ntile) {
+                const int mem = gtile / TPM, tm = gtile - mem * TPM;
+                const bool lo_w = tm >= 3 * KT;                   // one of the waves 3..5
+                const int ktw = lo_w ? KT - ODD : KT;
+                const int mw = lo_w ? 3 + (tm - 3 * KT) / ktw : tm / ktw;
+                const int tile0 = mem * TPM + mfma1_wave_tile0(mw, KT, ODD);   // first tile of the wave
+                const int ti = gtile - tile0;
+                const int NOP = 8 * ktw;
+                double* xw = XS + (size_t)tile0 * nit * 512;      // the wave's stream
+                const int oi = op_index(ti, sub, ktw);
                 const double vd = xt[ln & 15][16 * gl + 4 * sub + (ln >> 4)];
                 const double vu = xt[4 * sub + (ln >> 4)][16 * gl + (ln & 15)];
                 {
-                    const int ot = 4 * KT + oi;
-                    XS[(((size_t)wv * nit + b) * NOP + (ot & ~1)) * 64 + ln * 2 + (ot & 1)] = vd;
+                    const int ot = 4 * ktw + oi;
+                    xw[((size_t)b * NOP + (ot & ~1)) * 64 + ln * 2 + (ot & 1)] = vd;
                 }
-                if (has)
-                    XS[(((size_t)wv * nit + b + L) * NOP + (oi & ~1)) * 64 + ln * 2 + (oi & 1)] = vu;
-                if (b < L)
-                    XS[(((size_t)wv * nit + b) * NOP + (oi & ~1)) * 64 + ln * 2 + (oi & 1)] = 0.0;
+                if (has) xw[((size_t)(b + L) * NOP + (oi & ~1)) * 64 + ln * 2 + (oi & 1)] = vu;
+                if (b < L) xw[((size_t)b * NOP + (oi & ~1)) * 64 + ln * 2 + (oi & 1)] = 0.0;
             }
         }
 #pragma unroll
@@ -279,7 +287,9 @@ int mfma_kt_for(int64_t n, int T)
 
 // bytes of the block-packed operands for a sweep over p covariates of n rows
 // 16-row tiles per matrix wave of mfma_sweep1_kernel for n rows cut over CS workgroups
-// (T = tiles of 16 responses per cluster: 1, or 2 with CS = 2, 3, 4)
+// (T = tiles of 16 responses per cluster: 1, or 2 with CS = 2, 3)
+// Even deal: every matrix wave takes KT tiles.  mfma1_tiling_for() below prefers the odd deal
+// (waves 3..5 one tile fewer) when that covers n with fewer tiles per SIMD.
 int mfma1_kt_for(int64_t n, int CS, int T = 1)
 {
 #define LOCUS_KT_ITEM(k) k,
@@ -288,7 +298,7 @@ int mfma1_kt_for(int64_t n, int CS, int T = 1)
     static const int kts3[] = {LOCUS_MFMA1_KTS_C3(LOCUS_KT_ITEM) 0};
     static const int ktsT2[] = {LOCUS_MFMA1_KTS_T2(LOCUS_KT_ITEM) 0};
 #undef LOCUS_KT_ITEM
-    if (T == 2 && (CS < 2 || CS > 4)) return 0;
+    if (T == 2 && (CS < 2 || CS > 3)) return 0;
     if (T == 1 && (CS < 1 || CS > 3)) return 0;
     if (n > 2016) return 0;  // the matrix-core sweep's limit (mfma_kt_for)
     for (const int* kt = (T == 2) ? ktsT2 : (CS == 1) ? kts1 : (CS == 2 ? kts2 : kts3); *kt; ++kt)
@@ -296,13 +306,31 @@ int mfma1_kt_for(int64_t n, int CS, int T = 1)
     return 0;
 }
 
+// Row tiling of mfma_sweep1_kernel for n rows: {KT, ODD}, KT = 0 when not covered.  A SIMD (waves
+// m and m + 3) carries 2 KT - ODD tiles; the smallest such count that covers n wins.
+struct Tiling1 { int KT, ODD; };
+static Tiling1 mfma1_tiling_for(int64_t n, int CS, int T = 1)
+{
+    const int kt_even = mfma1_kt_for(n, CS, T);
+    if (kt_even == 0) return {0, 0};
+    // odd deal with the same KT: 3 CS (2 KT - 1) tiles.  Measured (n = 1000, p = 50 000, round 3): it
+    // pays where the operand fetch or the matrix work binds -- one workgroup per tile 17.6 -> 16.8
+    // ms, two 11.2 -> 10.5, two tiles on two 19.95 -> 18.9 -- and loses on clusters of three, which
+    // the chain binds (one tile 9.98 -> 10.4 ms, two tiles 13.8 -> 15.4): those keep the even deal.
+    const char* force = getenv("LOCUS_HIP_MFMA_EVEN");   // "1": always even, "0": odd wherever it fits
+    const bool want_odd = force ? force[0] == '0' : CS <= 2;
+    if (want_odd && kt_even >= 2 && (int64_t)3 * CS * (2 * kt_even - 1) * 16 >= n) return {kt_even, 1};
+    return {kt_even, 0};
+}
+static int tiling_rows(const Tiling1& t, int CS) { return CS * mfma1_member_tiles(t.KT, t.ODD) * 16; }
+
 // doubles of the mfma_sweep1_kernel layout for `nblk` blocks (largest look-ahead, both CS)
 static size_t mfma1_layout_doubles(int64_t n, size_t nblk, int cus)
 {
     const size_t nit = nblk + 5;
     size_t rows_pad = 0;
     for (int T = 1; T <= 2; ++T)
-        for (int CS = 1; CS <= 4; ++CS)
+        for (int CS = 1; CS <= 3; ++CS)
             rows_pad = std::max(rows_pad, (size_t)CS * 6 * 16 * mfma1_kt_for(n, CS, T));
     return nit * rows_pad * 32 + 2048      // XS (+ read-ahead slack)
            + nit * 256                     // cg
@@ -419,17 +447,18 @@ static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, i
 // One launch sequence of mfma_sweep1_kernel over responses [k_begin, k_end): packs (if `pack`) and
 // launches clusters of CS workgroups, at most as many clusters per launch as are resident at once
 // (a cluster's members wait for each other, so every member must be on a CU at the same time).
-static int pack_and_launch1(const SweepParams& prm, int T, int CS, int KT, int k_begin, int k_end,
+static int pack_and_launch1(const SweepParams& prm, int T, int CS, Tiling1 til, int k_begin, int k_end,
                             bool pack, void* xb_ws, size_t xb_bytes, hipStream_t st)
 {
     const int L = mfma1_lag(CS);
-    if (!((T == 1 && CS >= 1 && CS <= 3) || (T == 2 && CS >= 2 && CS <= 4))) {
+    const int KT = til.KT, ODD = til.ODD;
+    if (!((T == 1 && CS >= 1 && CS <= 3) || (T == 2 && CS >= 2 && CS <= 3))) {
         set_error("mfma sweep: no kernel for this (tiles per cluster, cluster size)");
         return LOCUS_HIP_EUNSUPPORTED;
     }
     const int NW = CS * 6;
-    const int rows_pad = NW * 16 * KT;
-    if (KT <= 0 || rows_pad < prm.n) {
+    const int rows_pad = tiling_rows(til, CS);
+    if (KT <= 0 || (ODD && KT < 2) || rows_pad < prm.n) {
         set_error("mfma sweep: geometry does not cover n rows");
         return LOCUS_HIP_EINVAL;
     }
@@ -456,14 +485,14 @@ static int pack_and_launch1(const SweepParams& prm, int T, int CS, int KT, int k
         const size_t lds = sizeof(double) * (size_t)L * 16 * 130 + sizeof(int) * 16 * L;
         if (L == 3) {
             hipLaunchKernelGGL(pack_blocks1_kernel<3>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
-                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps);
+                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD);
         } else {
             // 83 KB of dynamic LDS: above the 64 KB default limit.  The attribute belongs to the
             // (function, device) pair, so it is set before every launch (cheap; as in gemm.hip).
             LOCUS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pack_blocks1_kernel<5>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(pack_blocks1_kernel<5>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
-                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps);
+                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD);
         }
         LOCUS_HIP_CHECK(hipGetLastError());
     }
@@ -476,6 +505,7 @@ static int pack_and_launch1(const SweepParams& prm, int T, int CS, int KT, int k
     mp.cfac = prm.cfac;
     mp.R = prm.R; mp.state = prm.state; mp.st = prm.st;
     mp.xbuf = xbuf; mp.xflag = xflag;
+    mp.spread = getenv("LOCUS_HIP_TEST_SPREAD_MEMBERS") != nullptr;
     mp.drop_member = -1;
     if (const char* e = getenv("LOCUS_HIP_TEST_DROP_MEMBER")) mp.drop_member = atoi(e);
 
@@ -490,21 +520,20 @@ static int pack_and_launch1(const SweepParams& prm, int T, int CS, int KT, int k
         const int ke = std::min(k_end, k + TW * max_tiles);
         mp.k_begin = k; mp.k_end = ke;
         mp.ntiles = (ke - k + TW - 1) / TW;
-        if (CS > 1) {  // every exchange slot starts empty (kXEmpty), every end-of-sweep flag at zero
-            LOCUS_HIP_CHECK(hipMemsetAsync(xbuf, 0xFF, sizeof(unsigned long long) * mp.ntiles *
-                                                           xbuf_tile_words(CS, T), st));  // kXEmpty
+        if (CS > 1) {  // a granule / flag is valid when it carries this launch's tag: start from zero
+            LOCUS_HIP_CHECK(hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * mp.ntiles *
+                                                        xbuf_tile_words(CS, T), st));
             LOCUS_HIP_CHECK(hipMemsetAsync(xflag, 0, sizeof(int) * (size_t)mp.ntiles * CS * 32, st));
         }
         dim3 grid((unsigned)(((mp.ntiles + 7) / 8) * 8 * CS));
         int rc;
         if (T == 2)
-            rc = (CS == 2)   ? launch_mfma_sweep1_c2t2(mp, KT, grid, st)
-                 : (CS == 3) ? launch_mfma_sweep1_c3t2(mp, KT, grid, st)
-                             : launch_mfma_sweep1_c4t2(mp, KT, grid, st);
+            rc = (CS == 2) ? launch_mfma_sweep1_c2t2(mp, KT, ODD, grid, st)
+                           : launch_mfma_sweep1_c3t2(mp, KT, ODD, grid, st);
         else
-            rc = (CS == 1)   ? launch_mfma_sweep1_c1(mp, KT, grid, st)
-                 : (CS == 2) ? launch_mfma_sweep1_c2(mp, KT, grid, st)
-                             : launch_mfma_sweep1_c3(mp, KT, grid, st);
+            rc = (CS == 1)   ? launch_mfma_sweep1_c1(mp, KT, ODD, grid, st)
+                 : (CS == 2) ? launch_mfma_sweep1_c2(mp, KT, ODD, grid, st)
+                             : launch_mfma_sweep1_c3(mp, KT, ODD, grid, st);
         if (rc) return rc;
     }
     return 0;
@@ -543,9 +572,11 @@ static int choose_cs(int n, int tiles)
 //   A  = mfma_sweep_kernel<2, KT>: 32 responses on ONE CU, 7 matrix waves, the chain shares a
 //        SIMD with one of them; matrix-bound: 8.58 at KT = 9                       0.953 KT
 //   one tile of 16 responses on 1, 2, 3 CUs: bound by the operand fetch of the six matrix waves
-//        through the CU's L1 (5.63 at KT = 11, 3.42 at KT = 6)                     0.54 KT
+//        through the CU's L1: 5.63 at KT = 11 alone (0.512 KT), 3.58 at KT = 6 and 3.35 at
+//        KT = 5.5 (the odd deal) in a cluster of two (0.60 KT)
 //        or by the chain: 2.5 alone, 3.1 with the cluster hand-over (3.17 at CS = 3, KT = 4)
-//   two tiles (32 responses) on 2, 3, 4 CUs: matrix-bound (6.27 at KT = 6)         1.05 KT
+//   two tiles (32 responses) on 2, 3 CUs: matrix-bound (6.38 at KT = 6, 6.04 at 5.5)  1.10 KT
+//        (on 4 CUs: measured no faster than on 3 -- chain-bound -- and its helper spills: not built)
 //        or by the chain and the helper sharing a SIMD with twice the hand-over: 4.36
 // Members of a cluster must all be resident, so a cluster launch takes at most
 // floor(CUs / 8 CS) 8 clusters.  The plan minimises the sum of the launch durations over all ways
@@ -554,7 +585,7 @@ static int choose_cs(int n, int tiles)
 // ---------------------------------------------------------------------------
 struct LaunchType {
     int T, CS;      // CS = 0: mfma_sweep_kernel<2, KT> (one workgroup per 32 responses)
-    int KT;
+    int KT, ODD;
     int cap;        // responses one launch takes
     double cost;    // microseconds per block of 16 steps (model above)
 };
@@ -574,25 +605,35 @@ static std::vector<LaunchType> launch_types(int n)
     }
     const double pack = 0.2;
     if (const int kt = mfma_kt_for(n, 2); kt > 0 && (only_t == 0 || only_t == 1))
-        v.push_back({2, 0, kt, 32 * cus, 0.953 * kt + pack});
+        v.push_back({2, 0, kt, 0, 32 * cus, 0.953 * kt + pack});
     for (int T = 1; T <= 2; ++T)
-        for (int CS = (T == 1 ? 1 : 2); CS <= (T == 1 ? 3 : 4); ++CS) {
+        for (int CS = (T == 1 ? 1 : 2); CS <= 3; ++CS) {
             if (only_t != 0 && (T != only_t || CS != only_cs)) continue;
-            const int kt = mfma1_kt_for(n, CS, T);
+            const Tiling1 til = mfma1_tiling_for(n, CS, T);
+            const double kt = til.KT - 0.5 * til.ODD;     // tiles per matrix wave, SIMD average
             const int c = (CS == 1) ? cus : ccus;
-            if (kt == 0 || (CS > 1 && c < 8 * CS)) continue;
+            if (til.KT == 0 || (CS > 1 && c < 8 * CS)) continue;
             const int clusters = (CS == 1) ? c : (c / (8 * CS)) * 8;
             const double chain = (T == 2) ? 4.36 : ((CS == 1) ? 2.5 : 3.1);
-            const double work = (T == 2) ? 1.05 * kt : 0.54 * kt;
-            v.push_back({T, CS, kt, 16 * T * clusters, std::max(work, chain) + pack});
+            const double work = (T == 2) ? 1.10 * kt : (CS == 1 ? 0.512 : 0.60) * kt;
+            v.push_back({T, CS, til.KT, til.ODD, 16 * T * clusters, std::max(work, chain) + pack});
         }
     return v;
 }
 
+// G of an explicit geometry: 0 = the tiling the library picks; 1 .. 99 = KT tiles for every matrix
+// wave; 100 + KT = the odd deal (waves 3..5 take KT - 1)
+static Tiling1 explicit_tiling(int G, int n, int CS, int T)
+{
+    if (G <= 0) return mfma1_tiling_for(n, CS, T);
+    return G >= 100 ? Tiling1{G - 100, 1} : Tiling1{G, 0};
+}
+
 // cfg: C = T (tiles of 16 responses per cluster; 0 = plan by d), S = workgroups per cluster,
-// G = KT (16-row tiles per matrix wave, 0 = smallest instantiated value that covers n).
+// G = KT (16-row tiles per matrix wave, 0 = smallest instantiated value that covers n; 100 + KT =
+// waves 3..5 of every workgroup take KT - 1).
 //   C = 1: mfma_sweep1_kernel<KT, S>, S = 1, 2, 3 (0 = chosen from d; anything else = 1);
-//   C = 2: S = 2, 3, 4: mfma_sweep1_kernel<KT, S, 2> (two tiles per cluster);
+//   C = 2: S = 2, 3: mfma_sweep1_kernel<KT, S, 2> (two tiles per cluster);
 //          any other S: mfma_sweep_kernel<2, KT> (two tiles on one workgroup).
 int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
                    hipStream_t st)
@@ -605,12 +646,12 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
         // S = workgroups per cluster (1, 2, 3); 0 = chosen from d; anything else (legacy) = 1
         const int CS = (cfg.S == 2 || cfg.S == 3) ? cfg.S
                                                   : (cfg.S == 0 ? choose_cs(prm.n, (prm.d + 15) / 16) : 1);
-        const int KT = cfg.G > 0 ? cfg.G : mfma1_kt_for(prm.n, CS);
-        return pack_and_launch1(prm, 1, CS, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
+        return pack_and_launch1(prm, 1, CS, explicit_tiling(cfg.G, prm.n, CS, 1), 0, prm.d, true, xb_ws,
+                                xb_bytes, st);
     }
-    if (cfg.C == 2 && cfg.S >= 2 && cfg.S <= 4) {
-        const int KT = cfg.G > 0 ? cfg.G : mfma1_kt_for(prm.n, cfg.S, 2);
-        return pack_and_launch1(prm, 2, cfg.S, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
+    if (cfg.C == 2 && cfg.S >= 2 && cfg.S <= 3) {
+        return pack_and_launch1(prm, 2, cfg.S, explicit_tiling(cfg.G, prm.n, cfg.S, 2), 0, prm.d, true,
+                                xb_ws, xb_bytes, st);
     }
     if (cfg.C != 0) {
         const int KT = cfg.G > 0 ? cfg.G : mfma_kt_for(prm.n, cfg.C);
@@ -644,8 +685,8 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
         const bool pack = pick[u] != last;  // consecutive launches of one geometry share the operands
         const int rc = (lt.CS == 0)
                            ? pack_and_launch(prm, 2, lt.KT, k, k + take, pack, xb_ws, xb_bytes, st)
-                           : pack_and_launch1(prm, lt.T, lt.CS, lt.KT, k, k + take, pack, xb_ws, xb_bytes,
-                                              st);
+                           : pack_and_launch1(prm, lt.T, lt.CS, Tiling1{lt.KT, lt.ODD}, k, k + take, pack,
+                                              xb_ws, xb_bytes, st);
         if (rc) return rc;
         last = pick[u];
         k += take;

@@ -24,12 +24,17 @@
 //       finished one iteration ago to global memory and accumulates the fused column statistics.
 //
 // Row-split clusters (CS = 2, 3): the 16 responses' rows are cut over CS workgroups on CS CUs.
-// Each member projects / updates its own rows, publishes its partial G tile (2 KB per block and
-// tile) through global memory as 8-byte granules -- one double each, written and read with
-// agent-scope relaxed atomics; a slot that has not been written holds the sentinel ~0 (a NaN bit
-// pattern no arithmetic produces), so a granule is valid when it differs from it: no flag, no
-// fence in steady state --, and EVERY member runs the same chain on the same sums (added in member
-// order, so the chains are bit-identical and no delta ever has to travel).  The look-ahead is
+// Each member projects / updates its own rows, publishes its partial G tile (2 KB per block)
+// through global memory as tagged 8-byte granules {32 bits of a double, block + 1} written and
+// read with agent-scope relaxed atomics (a granule is valid when its tag matches: no flag, no
+// fence in steady state), and EVERY member runs the same chain on the same sums (added in member
+// order, so the chains are bit-identical and no delta ever has to travel).  The tag is what makes
+// the exchange safe when the members sit on different XCDs: an agent-scope load is served by the
+// reader's own L2, which other XCDs' stores never refresh, so a slot can read as what it held
+// sixteen blocks ago until the line is evicted -- stale data carries a stale tag and is fetched
+// again.  (Round 3 tried whole-double granules validated against an "empty" bit pattern, half
+// the loads and registers: right on a quiet GPU, where blocks b and b + 8 share an XCD; wrong
+// once in a while when other kernels were in flight at launch -- a stale line passes that test.)  The look-ahead is
 // deepened to L = 5 blocks so that a partial tile has two block times (~6 us) to arrive.  All
 // waits are bounded: a partner that does not show up raises the error word instead of hanging
 // the GPU.
@@ -60,22 +65,22 @@ struct Mfma1Params {
     double* state;        // [3][p][d]
     double* st;           // [4][d] or nullptr
     // CS > 1: exchange of the members' partial G tiles, [ntiles][kXTile] 8-byte words per cluster:
-    // kXRing slots x CS members x T x 256 granules (one double each; the host fills the buffer
-    // with the sentinel kXEmpty before every launch, and a member that publishes block b also
-    // resets its slot of block b + kXRing / 2 -- by then every member has consumed what it held,
-    // see the helper role), then CS x T x 64 doubles for the members' sums of squares of the
-    // residual at the end of the sweep
+    // kXRing slots x CS members x T x 512 granules {32 bits of a double, tag = block + 1} (zeroed by
+    // the host before every launch: a granule is valid when its tag matches), then CS x T x 64
+    // doubles for the members' sums of squares of the residual at the end of the sweep
     unsigned long long* xbuf;
     int* xflag;           // CS > 1: [ntiles][CS][32] end-of-sweep flags of the members
+    int spread;           // test hook (LOCUS_HIP_TEST_SPREAD_MEMBERS): members of a cluster are
+                          // CONSECUTIVE workgroups, i.e. on different XCDs under round-robin
+                          // placement -- the exchange must not depend on sharing an L2
     int drop_member;      // test hook (LOCUS_HIP_TEST_DROP_MEMBER): this member of every cluster
                           // returns at entry, as a workgroup that was never dispatched; -1 = none
 };
 
 constexpr int kXRing = 16;  // exchange slots per member; >= 2 L + 1 blocks can be in flight
-constexpr unsigned long long kXEmpty = ~0ull;  // "not written yet" (hipMemsetAsync with 0xFF)
 __host__ __device__ constexpr size_t xbuf_tile_words(int CS, int T = 1)
 {
-    return ((size_t)kXRing * CS * 256 + CS * 64) * T;
+    return ((size_t)kXRing * CS * 512 + CS * 64) * T;
 }
 
 __host__ __device__ constexpr int mfma1_lag(int CS) { return CS == 1 ? 3 : 5; }
@@ -136,17 +141,28 @@ __device__ unsigned long long g_mfma1_stamps[4096 * 4 * 8];
 #define M1STAMP_FLUSH(role) do { } while (0)
 #endif
 
-template <int KT, int CS, int T = 1>
+// Rows per matrix wave.  The six matrix waves of a workgroup sit two to a SIMD (waves m and m + 3
+// of the matrix role); what bounds a block is the work of a SIMD, so the rows are dealt in 16-row
+// tiles per SIMD: waves 0..2 take KT tiles each, waves 3..5 take KT - ODD.  With ODD = 1 a SIMD
+// carries 2 KT - 1 tiles -- n = 1000 on three workgroups is 63 tiles = 9 SIMDs x 7 exactly, where
+// an even deal (8 per SIMD) makes every SIMD multiply 14 % of padding.
+__host__ __device__ constexpr int mfma1_member_tiles(int KT, int ODD) { return 3 * KT + 3 * (KT - ODD); }
+__host__ __device__ constexpr int mfma1_wave_tile0(int m, int KT, int ODD)
+{
+    return m < 3 ? m * KT : 3 * KT + (m - 3) * (KT - ODD);
+}
+
+template <int KT, int CS, int T = 1, int ODD = 0>
 __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 {
+    static_assert(ODD == 0 || (ODD == 1 && KT >= 2), "the short waves keep at least one tile");
     static_assert(T == 1 || T == 2, "one or two tiles of 16 responses per cluster");
     static_assert(T == 1 || CS > 1, "two tiles on ONE workgroup is mfma_sweep_kernel<2, KT>");
     constexpr int L = mfma1_lag(CS);
     constexpr int MW = 6;
-    constexpr int NOP = 8 * KT, NPAIR = NOP / 2, NR2 = ring1_pairs<KT, T>();
+    constexpr int TPM = mfma1_member_tiles(KT, ODD);   // 16-row tiles of a workgroup
     constexpr int TW = 16 * T;          // responses of a cluster = row length of the [t][k] LDS arrays
     constexpr int TB = 256 * T;         // doubles of one 16 x 16 T block of them
-    static_assert(NPAIR % NR2 == 0, "ring must divide the iteration stream");
     constexpr int DR = 8;       // delta ring, blocks (power of two, >= L)
     constexpr int CHAIN_W = 3, HELP_W = 7;
 
@@ -182,8 +198,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     // cluster g = tile of 16 responses, member c = slice of the rows; members of a cluster have
     // equal blockIdx % 8 (same XCD under round-robin placement: speed only, never correctness)
     const int bi = blockIdx.x;
-    const int g_cl = (bi / (8 * CS)) * 8 + (bi & 7);
-    const int c_mem = (bi >> 3) % CS;
+    const int g_cl = P.spread ? bi / CS : (bi / (8 * CS)) * 8 + (bi & 7);
+    const int c_mem = P.spread ? bi % CS : (bi >> 3) % CS;
     if (g_cl >= P.ntiles || *P.err != 0) return;
     if (CS > 1 && c_mem == P.drop_member) return;
     const int k0 = P.k_begin + TW * g_cl;
@@ -208,23 +224,30 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     if (w != CHAIN_W && w != HELP_W) {
         // =========================== matrix role ==========================================
         const int m = (w > CHAIN_W) ? w - 1 : w;
-        const int row0 = ((c_mem * MW + m) * KT) * 16;
+        // the role is written once for a wave of KTW tiles and instantiated for KT and, with ODD,
+        // for KT - 1 (waves 3..5)
+        auto matrix_role = [&](auto ktw_c) {
+        constexpr int KTW = decltype(ktw_c)::value;
+        constexpr int NOP = 8 * KTW, NPAIR = NOP / 2, NR2 = ring1_pairs<KTW, T>();
+        static_assert(NPAIR % NR2 == 0, "ring must divide the iteration stream");
+        const int tile0 = c_mem * TPM + mfma1_wave_tile0(m, KT, ODD);
+        const int row0 = tile0 * 16;
 
-        d4 rv[T][KT];
+        d4 rv[T][KTW];
 #pragma unroll
         for (int tau = 0; tau < T; ++tau) {
             const int k = k0 + 16 * tau + r;
             const double* Rk = P.R + (size_t)(k < kend ? k : 0) * n;
 #pragma unroll
-            for (int i = 0; i < KT; ++i)
+            for (int i = 0; i < KTW; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int row = row0 + 16 * i + 4 * g + q;
                     rv[tau][i][g] = (k < kend && row < n) ? Rk[row] : 0.0;
                 }
         }
-        const double2* xp = reinterpret_cast<const double2*>(P.XS) +
-                            ((size_t)(c_mem * MW + m) * nit) * NPAIR * 64 + lane;
+        // the waves' streams follow one another: a tile contributes 8 operands = 4 pairs per iteration
+        const double2* xp = reinterpret_cast<const double2*>(P.XS) + (size_t)tile0 * nit * 4 * 64 + lane;
         double2 ring[NR2];
 #pragma unroll
         for (int i = 0; i < NR2; ++i) {
@@ -330,15 +353,15 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     ring[sl] = *xp;
                     xp += 64;
                 }
-                if constexpr (o < 4 * KT) {  // R += X_{it-L} d_{it-L}
-                    constexpr int i = op_tile(o, KT), c = op_sub(o, KT);
+                if constexpr (o < 4 * KTW) {  // R += X_{it-L} d_{it-L}
+                    constexpr int i = op_tile(o, KTW), c = op_sub(o, KTW);
                     sfor<T>([&](auto tc) {
                         constexpr int tau = decltype(tc)::value;
                         rv[tau][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[c][tau], rv[tau][i],
                                                                           0, 0, 0);
                     });
                 } else {                     // partial G_it = X_it' R over this wave's rows
-                    constexpr int i = op_tile(o - 4 * KT, KT), g = op_sub(o - 4 * KT, KT);
+                    constexpr int i = op_tile(o - 4 * KTW, KTW), g = op_sub(o - 4 * KTW, KTW);
                     sfor<T>([&](auto tc) {
                         constexpr int tau = decltype(tc)::value;
                         constexpr int a2 = (NACC == 2) ? (i & 1) : 0;
@@ -437,7 +460,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             double* Rk = P.R + (size_t)(k < d_e ? k : 0) * n_e;
             double a0 = 0.0;
 #pragma unroll
-            for (int i = 0; i < KT; ++i)
+            for (int i = 0; i < KTW; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int row = row0 + 16 * i + 4 * g + q_e;
@@ -448,6 +471,13 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             part[(m * T + tau) * 64 + lane] = a0;
         }
         __syncthreads();  // E2
+        };  // matrix_role
+        if constexpr (ODD == 1) {
+            if (m < 3) matrix_role(std::integral_constant<int, KT>{});
+            else matrix_role(std::integral_constant<int, KT - 1>{});
+        } else {
+            matrix_role(std::integral_constant<int, KT>{});
+        }
     } else if (w == CHAIN_W) {
         // =========================== chain role ===========================================
         const int kc = k0 + lane;
@@ -746,12 +776,12 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             xb_tile = P.xbuf + (size_t)g_cl * xbuf_tile_words(CS, T);
             xf_tile = P.xflag + (size_t)g_cl * CS * 32;
         }
-        constexpr int NGV = (CS > 1) ? CS * 4 * T : 1;   // granules per lane and block
+        constexpr int NGV = (CS > 1) ? CS * 8 * T : 1;   // granules per lane and block
 
         // CS > 1: the members' partial tiles of the block whose reduced G is due in the NEXT
-        // iteration, one granule per double: fetched one iteration ahead, validated (and in the
-        // rare case of a late partner re-fetched) when they are due
-        // (index (cm * T + tau) * 4 + g: member cm, tile tau, accumulator register g of the lane)
+        // iteration, as granules {half a double, tag}: fetched one iteration ahead, validated (and
+        // in the rare case of a late partner re-fetched) when they are due
+        // (index (cm * T + tau) * 8 + e: member cm, tile tau, granule e of the lane)
         unsigned long long gv[NGV];
 #pragma unroll
         for (int e = 0; e < NGV; ++e) gv[e] = 0ull;
@@ -789,8 +819,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) sg[tau][g] = 0.0;
                 if (bn_blk >= 0 && bn_blk < P.nblk) {
+                    const unsigned tag = (unsigned)bn_blk + 1u;
                     const unsigned long long* gsrc =
-                        xb_tile + (size_t)(bn_blk % kXRing) * CS * T * 256 + lane;
+                        xb_tile + (size_t)(bn_blk % kXRing) * CS * T * 512 + lane;
                     // The granules were fetched one iteration ago and the wait of that iteration's
                     // hand-over covered them: the check below must not wait for anything.  (Written
                     // as one loop -- check, break, sleep, refetch -- the compiler put a vmcnt(0) in
@@ -799,7 +830,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     auto tags_ok = [&]() {
                         bool ok = true;
 #pragma unroll
-                        for (int e = 0; e < NGV; ++e) ok = ok && (gv[e] != kXEmpty);
+                        for (int e = 0; e < NGV; ++e) ok = ok && ((unsigned)(gv[e] >> 32) == tag);
                         return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
                     };
                     if (!tags_ok()) {  // a partner is late: poll
@@ -830,8 +861,12 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #pragma unroll
                         for (int tau = 0; tau < T; ++tau)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g)
-                                sg[tau][g] += __longlong_as_double((long long)gv[(cm * T + tau) * 4 + g]);
+                            for (int g = 0; g < 4; ++g) {
+                                const int e0 = (cm * T + tau) * 8 + 2 * g;
+                                const unsigned long long lo = gv[e0] & 0xffffffffull;
+                                const unsigned long long hi = gv[e0 + 1] << 32;
+                                sg[tau][g] += __longlong_as_double((long long)(hi | lo));
+                            }
                 }
 #pragma unroll
                 for (int tau = 0; tau < T; ++tau)
@@ -891,7 +926,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 const int bg = bn_blk + 1;
                 if (bg >= 0 && bg < P.nblk) {
                     const unsigned long long* gsrc =
-                        xb_tile + (size_t)(bg % kXRing) * CS * T * 256 + lane;
+                        xb_tile + (size_t)(bg % kXRing) * CS * T * 512 + lane;
 #pragma unroll
                     for (int e = 0; e < NGV; ++e)
                         gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -947,28 +982,20 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             if constexpr (CS > 1) {
                 // ---- publish this member's partial tile of block it - 1 ---------------------------
                 if (it >= 1 && it - 1 < P.nblk) {
-                    // Block it - 1 goes to ring slot (it - 1) % kXRing; the slot half a ring ahead,
-                    // which held block it - 1 - kXRing / 2, is reset to "empty" for block it - 1 +
-                    // kXRing / 2.  Nobody can still want the old block: this member validated block
-                    // it - L + 2 of EVERY member at the top of this iteration, so all members have
-                    // passed their iteration it - L + 3 = it - 2, and a block B is validated for
-                    // the last time in iteration B + L - 2 (here: it - 1 - 8 + 3 = it - 6).  And the
-                    // reset is visible in time: this wave waits for all its stores once per
-                    // iteration (the hand-over wait), three iterations and more before a reader
-                    // may look at the slot again.
+                    const unsigned long long tagw = (unsigned long long)(unsigned)it << 32;  // block + 1
                     unsigned long long* slot =
-                        xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * T * 256 + lane;
-                    unsigned long long* slot_rst =
-                        xb_tile + ((size_t)((it - 1 + kXRing / 2) % kXRing) * CS + c_mem) * T * 256 + lane;
+                        xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * T * 512 + lane;
 #pragma unroll
                     for (int tau = 0; tau < T; ++tau)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            __hip_atomic_store(slot + 256 * tau + 64 * g,
-                                               (unsigned long long)__double_as_longlong(pg[tau][g]),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(slot_rst + 256 * tau + 64 * g, kXEmpty, __ATOMIC_RELAXED,
+                            const unsigned long long bits =
+                                (unsigned long long)__double_as_longlong(pg[tau][g]);
+                            __hip_atomic_store(slot + 512 * tau + 64 * (2 * g),
+                                               tagw | (bits & 0xffffffffull), __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(slot + 512 * tau + 64 * (2 * g + 1), tagw | (bits >> 32),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                 }
             }
@@ -1025,7 +1052,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         }
         if (CS > 1 && alive) {
             // sum of squares over the members' row slices, added in member order by member 0
-            double* rs_base = reinterpret_cast<double*>(xb_tile + (size_t)kXRing * CS * T * 256);
+            double* rs_base = reinterpret_cast<double*>(xb_tile + (size_t)kXRing * CS * T * 512);
             if (lane < 16) {
 #pragma unroll
                 for (int tau = 0; tau < T; ++tau)

@@ -70,11 +70,11 @@ def main():
                                   (1, "chain", ["busy", "wait", "->U", "->delta"])):
                 med = np.median(a[:, ro, :len(names)], axis=0)
                 print(f"   ticks/step {nm:14s}: " + " ".join(f"{k}={v:.0f}" for k, v in zip(names, med)))
-        elif "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0 and (cfg[1] == 1 or (cfg[1] == 2 and cfg[2] in (2, 3, 4))):
+        elif "diag" in _lib.LIB_PATH and cfg and cfg[0] < 0 and (cfg[1] == 1 or (cfg[1] == 2 and cfg[2] in (2, 3))):
             import ctypes
             import os
             t2 = cfg[1] == 2
-            cs_used = cfg[2] if cfg[2] in (2, 3, 4) else int(os.environ.get("LOCUS_HIP_MFMA_CS", "1"))
+            cs_used = cfg[2] if cfg[2] in (2, 3) else int(os.environ.get("LOCUS_HIP_MFMA_CS", "1"))
             fn = getattr(ctypes.CDLL(_lib.LIB_PATH),
                          f"locus_hip_diag_read_mfma1_stamps_c{cs_used}" + ("t2" if t2 else ""))
             nwg = min(4096, cs_used * ((d + 15) // (32 if t2 else 16) + 8))

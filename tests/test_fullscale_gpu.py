@@ -94,6 +94,8 @@ FULL = [  # variant, n, p, d, sweeps, forced geometry (None = what the library p
     ("identity", 1000, 50000, 48, 2, None),          # C3's chain, two sweeps in a row
     ("identity", 1000, 50000, 48, 2, "-1,2,0,0"),    # the T = 2 launch of the C3 plan
     ("identity", 1000, 50000, 48, 2, "-1,1,0,0"),    # its T = 1 remainder / every multi-GPU shard
+    ("identity", 1000, 50000, 48, 2, "-1,1,2,0"),    # one tile on two workgroups, the odd row deal
+    ("identity", 1000, 50000, 48, 2, "-1,2,3,0"),    # two tiles per cluster of three (4-GPU shard)
     ("struct", 1000, 50000, 40, 1, None),            # C5's chain
     ("struct", 1000, 50000, 40, 1, "-1,2,0,0"),
 ]
@@ -118,6 +120,24 @@ def test_full_length_chain_matches_oracle(oracle, hip, variant, n, p, d, sweeps,
               f"min |gam - 0.5| = {np.abs(refs[s]['gam_vb'] - 0.5).min():.3e}; selected "
               f"{int((refs[s]['gam_vb'] > 0.5).sum())}")
         cur = dict(cur, **got)      # the HIP path continues from its OWN output
+
+
+@pytest.mark.parametrize("geom", ["-1,1,3,0", "-1,1,2,0", "-1,2,3,0"])
+def test_cluster_exchange_across_xcds(oracle, hip, geom, monkeypatch):
+    """The members of a row-split cluster normally sit 8 workgroups apart (one XCD, one L2).  HIP
+    promises no placement, so the exchange must also be right across XCDs, whose L2s do not see
+    each other's stores: LOCUS_HIP_TEST_SPREAD_MEMBERS makes the members consecutive workgroups
+    (different XCDs under round-robin placement).  Full-length chain (3125 blocks: the exchange
+    ring is reused ~200 times, so a slot read back as what it held a lap ago would show)."""
+    inp, orders, refs = _case(oracle, "identity", 1000, 50000, 48, 2)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", geom)
+    monkeypatch.setenv("LOCUS_HIP_TEST_SPREAD_MEMBERS", "1")
+    cur = inp
+    for s in range(2):
+        cur = dict(cur, shuffled_ind=orders[s])
+        got = call_variant(hip, "identity", cur)
+        _assert_parity_full(got, refs[s], f"identity spread members geom={geom} sweep {s + 1}")
+        cur = dict(cur, **got)
 
 
 ATOL_FULL = 5e-13   # absolute floor for full-length chains (see _assert_parity_full)
