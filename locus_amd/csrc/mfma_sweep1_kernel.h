@@ -613,23 +613,22 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     const double num = (a >= 0.0) ? e : 1.0;
                     corr_upd(integral_constant<int, 6>{});
                     LOCUS_FENCE();
-                    double rcp = __builtin_amdgcn_rcp(den);                    // div_1to2 (fastmath.h)
+                    // div_1to2 (fastmath.h): the hardware reciprocal (2^-24.4), ONE Newton step and
+                    // the quotient's own correction below -- 0.5 ulp like the two-step form
+                    // (scripts/microbench/div_accuracy.hip), two dependent instructions shorter
+                    double rcp = __builtin_amdgcn_rcp(den);
                     corr_upd(integral_constant<int, 7>{});
                     corr_upd(integral_constant<int, 8>{});
+                    corr_upd(integral_constant<int, 9>{});
                     LOCUS_FENCE();
                     double tt = fma(-den, rcp, 1.0);
-                    corr_upd(integral_constant<int, 9>{});
                     corr_upd(integral_constant<int, 10>{});
-                    LOCUS_FENCE();
-                    rcp = fma(tt, rcp, rcp);
                     corr_upd(integral_constant<int, 11>{});
                     corr_upd(integral_constant<int, 12>{});
-                    LOCUS_FENCE();
-                    tt = fma(-den, rcp, 1.0);
-                    corr_upd(integral_constant<int, 13>{});
                     if constexpr (t + 1 < kBlk) base = fma(sc_n.y, bo_n, gx_n);
                     LOCUS_FENCE();
                     rcp = fma(tt, rcp, rcp);
+                    corr_upd(integral_constant<int, 13>{});
                     if constexpr (t + 1 < kBlk) {
                         pre = fma(gc[t + 1], bo_c, corr[t + 1]);
                         gm = gc[t + 1] * m;
