@@ -25,8 +25,8 @@
 //
 // Row-split clusters (CS = 2, 3): the 16 responses' rows are cut over CS workgroups on CS CUs.
 // Each member projects / updates its own rows, publishes its partial G tile (2 KB per block)
-// through global memory as tagged 8-byte granules {32 bits of a double, block + 1} written and
-// read with agent-scope relaxed atomics (a granule is valid when its tag matches: no flag, no
+// through global memory as tagged 16-byte granules {block + 1, one double, block + 1} written and
+// read as single sc1 (agent-scope) accesses (a granule is valid when both tags match: no flag, no
 // fence in steady state), and EVERY member runs the same chain on the same sums (added in member
 // order, so the chains are bit-identical and no delta ever has to travel).  The tag is what makes
 // the exchange safe when the members sit on different XCDs: an agent-scope load is served by the
@@ -65,9 +65,9 @@ struct Mfma1Params {
     double* state;        // [3][p][d]
     double* st;           // [4][d] or nullptr
     // CS > 1: exchange of the members' partial G tiles, [ntiles][kXTile] 8-byte words per cluster:
-    // kXRing slots x CS members x T x 512 granules {32 bits of a double, tag = block + 1} (zeroed by
-    // the host before every launch: a granule is valid when its tag matches), then CS x T x 64
-    // doubles for the members' sums of squares of the residual at the end of the sweep
+    // kXRing slots x CS members x T x 256 granules of 16 bytes {tag, double, tag}, tag = block + 1
+    // (zeroed by the host before every launch: a granule is valid when both tags match), then
+    // CS x T x 64 doubles for the members' sums of squares of the residual at the end of the sweep
     unsigned long long* xbuf;
     int* xflag;           // CS > 1: [ntiles][CS][32] end-of-sweep flags of the members
     int spread;           // test hook (LOCUS_HIP_TEST_SPREAD_MEMBERS): members of a cluster are
@@ -78,6 +78,8 @@ struct Mfma1Params {
 };
 
 constexpr int kXRing = 16;  // exchange slots per member; >= 2 L + 1 blocks can be in flight
+typedef unsigned int xgran __attribute__((ext_vector_type(4)));  // {tag, low, high, tag}
+constexpr int kXAuxSc1 = 16;  // cache-policy operand of the raw buffer intrinsics on gfx94x/95x: sc1
 __host__ __device__ constexpr size_t xbuf_tile_words(int CS, int T = 1)
 {
     return ((size_t)kXRing * CS * 512 + CS * 64) * T;
@@ -175,8 +177,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     __shared__ __align__(16) double bol[2 * TB];         // beta_old                    [par][t][k]
     __shared__ __align__(16) double gram[2 * 256];       // Gram columns of a chain block [par][t][t2]
     __shared__ __align__(16) double scl[2 * 32];         // lod, xtx of its steps       [par][t][2]
-    // CS > 1: A operands of the cross-block corrections of a block, staged by the helper [par][lag][lane][4]
-    __shared__ __align__(16) double axl[(CS > 1) ? 2 * (L - 1) * 256 : 2];
+    // CS > 1: A operands of the lag-1 cross-block correction of a block, staged by the helper [par][lane][4]
+    __shared__ __align__(16) double axl[(CS > 1) ? 2 * 256 : 2];
     // CS > 1: corrections of the lags 2 .. L-1 (matrix waves 1 .. L-2), D layout, and their flags
     __shared__ __align__(16) double cx[(CS > 1) ? (L - 2) * TB : 2];
     __shared__ int cxf[4];
@@ -255,6 +257,22 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             xp += 64;
         }
         const size_t ax_lag = (size_t)(nit + 1) * 256;   // doubles per lag in P.ax
+        // clusters: matrix waves 1 .. L-2 form the cross-block correction of one known lag each
+        // (lag m + 1); its A operands come straight from global memory, requested one iteration
+        // before they are used (they used to travel through the helper and LDS: 24 registers, six
+        // loads and six LDS stores per block on the SIMD that the chain needs)
+        double2 axn[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+        auto ax_request = [&](int bxn) {
+            if constexpr (CS > 1) {
+                if (m >= 1 && m <= L - 2 && bxn >= 0 && bxn < P.nblk) {
+                    const double2* ap = reinterpret_cast<const double2*>(
+                        P.ax + (size_t)m * ax_lag + (size_t)bxn * 256 + 4 * lane);
+                    axn[0] = ap[0];
+                    axn[1] = ap[1];
+                }
+            }
+        };
+        ax_request(2 - L);
 
         for (int it = 0; it < nit; ++it) {
             const int par = it & 1;
@@ -296,11 +314,10 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 // (requests only; the MFMAs and the result go into the operand stream below, a
                 // quarter and a half of the way through, so that neither the LDS latency nor the
                 // latency of four dependent MFMAs is paid at the top of the iteration)
+                axr[0][0] = axn[0];
+                axr[0][1] = axn[1];
+                ax_request(bx + 1);
                 if (do_corr) {
-                    const double2* ap =
-                        reinterpret_cast<const double2*>(axl + ((bx & 1) * (L - 1) + m) * 256) + 2 * lane;
-                    axr[0][0] = ap[0];
-                    axr[0][1] = ap[1];
                     const double* dp = dl + ((bx - (m + 1)) & (DR - 1)) * TB + q * TW + r;
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
@@ -674,8 +691,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #pragma unroll
                     for (int l = 2; l < L; ++l) fl[l - 1] = lds_peek(&cxf[l - 2]);
                     asm volatile("" ::: "memory");  // flags first: the LDS serves a wave in order
-                    const double2* ap =
-                        reinterpret_cast<const double2*>(axl + ((bx & 1) * (L - 1)) * 256) + 2 * lane;
+                    const double2* ap = reinterpret_cast<const double2*>(axl + (bx & 1) * 256) + 2 * lane;
                     const double2 a01 = ap[0], a23 = ap[1];
                     const double* dp = dl + ((bx - 1) & (DR - 1)) * TB + q * TW + r;
                     double b4[4][T], gq[T][4], cq[L - 2][T][4];
@@ -775,15 +791,33 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             xb_tile = P.xbuf + (size_t)g_cl * xbuf_tile_words(CS, T);
             xf_tile = P.xflag + (size_t)g_cl * CS * 32;
         }
-        constexpr int NGV = (CS > 1) ? CS * 8 * T : 1;   // granules per lane and block
+        constexpr int NGV = (CS > 1) ? CS * 4 * T : 1;   // granules per lane and block
 
         // CS > 1: the members' partial tiles of the block whose reduced G is due in the NEXT
-        // iteration, as granules {half a double, tag}: fetched one iteration ahead, validated (and
-        // in the rare case of a late partner re-fetched) when they are due
-        // (index (cm * T + tau) * 8 + e: member cm, tile tau, granule e of the lane)
-        unsigned long long gv[NGV];
+        // iteration, as 16-byte granules {tag, low half, high half, tag} of one double each:
+        // fetched one iteration ahead, validated (and in the rare case of a late partner
+        // re-fetched) when they are due.  A granule is one 16-byte sc1 store and one 16-byte sc1
+        // load; the tag on BOTH sides of the data means that a granule seen half old, half new
+        // (8-byte tearing; not observed on gfx950) fails the check like a stale one.  Round 2's
+        // 8-byte granules {tag, half a double} cost this wave two loads, two compares and three
+        // integer instructions of re-assembly per double -- on the SIMD it shares with the chain.
+        // Addresses: the cluster's exchange area is a buffer resource, the lane offset a
+        // loop-invariant register, everything else scalar (no vector address arithmetic).
+        // (index (cm * T + tau) * 4 + g: member cm, tile tau, accumulator register g of the lane)
+        xgran gv[NGV];
 #pragma unroll
-        for (int e = 0; e < NGV; ++e) gv[e] = 0ull;
+        for (int e = 0; e < NGV; ++e) gv[e] = xgran{0u, 0u, 0u, 0u};
+        __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)xb_tile, 0, 0x7fffffff, 0x00020000 /* 32-bit data format, gfx9 */);
+        const int xvoff = lane * 16;
+        constexpr int kXBlockBytes = CS * T * 4 * 1024;   // one ring slot: CS members x T tiles x 4 x 64 granules
+        auto fetch_granules = [&](int blk) {
+            const int sbase = (blk % kXRing) * kXBlockBytes;
+#pragma unroll
+            for (int e = 0; e < NGV; ++e)
+                gv[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff + (e & 3) * 1024,
+                                                              sbase + (e >> 2) * 4096, kXAuxSc1);
+        };
 
         for (int it = 0; it < nit; ++it) {
             __syncthreads();  // B1
@@ -819,8 +853,6 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     for (int g = 0; g < 4; ++g) sg[tau][g] = 0.0;
                 if (bn_blk >= 0 && bn_blk < P.nblk) {
                     const unsigned tag = (unsigned)bn_blk + 1u;
-                    const unsigned long long* gsrc =
-                        xb_tile + (size_t)(bn_blk % kXRing) * CS * T * 512 + lane;
                     // The granules were fetched one iteration ago and the wait of that iteration's
                     // hand-over covered them: the check below must not wait for anything.  (Written
                     // as one loop -- check, break, sleep, refetch -- the compiler put a vmcnt(0) in
@@ -829,7 +861,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     auto tags_ok = [&]() {
                         bool ok = true;
 #pragma unroll
-                        for (int e = 0; e < NGV; ++e) ok = ok && ((unsigned)(gv[e] >> 32) == tag);
+                        for (int e = 0; e < NGV; ++e) ok = ok && (gv[e].x == tag) && (gv[e].w == tag);
                         return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
                     };
                     if (!tags_ok()) {  // a partner is late: poll
@@ -843,10 +875,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #ifdef LOCUS_STAMPS
                             tacc[7] += 1;  // refetches
 #endif
-#pragma unroll
-                            for (int e = 0; e < NGV; ++e)
-                                gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT);
+                            asm volatile("" ::: "memory");   // a fresh fetch every pass
+                            fetch_granules(bn_blk);
                             // pin: the wait for these loads is issued HERE, on the slow path, and
                             // the registers leave it with nothing pending
 #pragma unroll
@@ -861,10 +891,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                         for (int tau = 0; tau < T; ++tau)
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
-                                const int e0 = (cm * T + tau) * 8 + 2 * g;
-                                const unsigned long long lo = gv[e0] & 0xffffffffull;
-                                const unsigned long long hi = gv[e0 + 1] << 32;
-                                sg[tau][g] += __longlong_as_double((long long)(hi | lo));
+                                const xgran v = gv[(cm * T + tau) * 4 + g];
+                                sg[tau][g] += __hiloint2double((int)v.z, (int)v.y);
                             }
                 }
 #pragma unroll
@@ -886,19 +914,13 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             int jv = 0;
             const int jn_blk = bn_blk + 1;   // its covariates are staged one more iteration ahead
             if (lane < 16 && jn_blk >= 0 && jn_blk < P.nblk) jv = P.jidx[16 * jn_blk + lane];
-            double2 ax_v[(CS > 1) ? L - 1 : 1][2];
-#pragma unroll
-            for (int l = 0; l < ((CS > 1) ? L - 1 : 1); ++l)
-                ax_v[l][0] = ax_v[l][1] = make_double2(0.0, 0.0);
-            if constexpr (CS > 1) {  // and the A operands of its cross-block corrections
+            double2 ax_v[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+            if constexpr (CS > 1) {  // and the A operands of its lag-1 correction (the chain wave's)
                 if (jn_blk >= 0 && jn_blk < P.nblk) {
-#pragma unroll
-                    for (int l = 1; l < L; ++l) {
-                        const double2* ap = reinterpret_cast<const double2*>(
-                            P.ax + ((size_t)(l - 1) * (nit + 1) + jn_blk) * 256 + 4 * lane);
-                        ax_v[l - 1][0] = ap[0];
-                        ax_v[l - 1][1] = ap[1];
-                    }
+                    const double2* ap =
+                        reinterpret_cast<const double2*>(P.ax + (size_t)jn_blk * 256 + 4 * lane);
+                    ax_v[0] = ap[0];
+                    ax_v[1] = ap[1];
                 }
             }
             if (bn_blk >= 0 && bn_blk < P.nblk) {
@@ -923,13 +945,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             if constexpr (CS > 1) {
                 // ---- granules of the block due next iteration (published a whole iteration ago) ---
                 const int bg = bn_blk + 1;
-                if (bg >= 0 && bg < P.nblk) {
-                    const unsigned long long* gsrc =
-                        xb_tile + (size_t)(bg % kXRing) * CS * T * 512 + lane;
-#pragma unroll
-                    for (int e = 0; e < NGV; ++e)
-                        gv[e] = __hip_atomic_load(gsrc + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (bg >= 0 && bg < P.nblk) fetch_granules(bg);
                 // ---- this member's partial tile of block it - 1: reduce (published below) --------
                 if (it >= 1 && it - 1 < P.nblk) {
                     const double* pp = part + (((it - 1) & 1) * MW) * TB + lane;
@@ -965,12 +981,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             if (lane < 16) jl[(jn_blk & 7) * 16 + lane] = jv;
             if constexpr (CS > 1) {
                 if (jn_blk >= 0 && jn_blk < P.nblk) {
-                    double2* ap = reinterpret_cast<double2*>(axl + (jn_blk & 1) * (L - 1) * 256) + 2 * lane;
-#pragma unroll
-                    for (int l = 0; l < L - 1; ++l) {
-                        ap[128 * l] = ax_v[l][0];
-                        ap[128 * l + 1] = ax_v[l][1];
-                    }
+                    double2* ap = reinterpret_cast<double2*>(axl + (jn_blk & 1) * 256) + 2 * lane;
+                    ap[0] = ax_v[0];
+                    ap[1] = ax_v[1];
                 }
                 // the granules just fetched are complete as well: pin them before the stores
 #pragma unroll
@@ -981,20 +994,25 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             if constexpr (CS > 1) {
                 // ---- publish this member's partial tile of block it - 1 ---------------------------
                 if (it >= 1 && it - 1 < P.nblk) {
-                    const unsigned long long tagw = (unsigned long long)(unsigned)it << 32;  // block + 1
-                    unsigned long long* slot =
-                        xb_tile + ((size_t)((it - 1) % kXRing) * CS + c_mem) * T * 512 + lane;
+                    const unsigned tagw = (unsigned)it;  // block + 1
+                    const int sbase = ((it - 1) % kXRing) * kXBlockBytes + c_mem * T * 4096;
 #pragma unroll
                     for (int tau = 0; tau < T; ++tau)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const unsigned long long bits =
-                                (unsigned long long)__double_as_longlong(pg[tau][g]);
-                            __hip_atomic_store(slot + 512 * tau + 64 * (2 * g),
-                                               tagw | (bits & 0xffffffffull), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(slot + 512 * tau + 64 * (2 * g + 1), tagw | (bits >> 32),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const xgran v = xgran{tagw, (unsigned)__double2loint(pg[tau][g]),
+                                                  (unsigned)__double2hiint(pg[tau][g]), tagw};
+                            __builtin_amdgcn_raw_buffer_store_b128(v, xrs, xvoff + g * 1024,
+                                                                   sbase + tau * 4096, kXAuxSc1);
+                            // A 16-byte store reads its data registers AFTER it has issued, and the
+                            // compiler reuses them for the next granule in the very next
+                            // instruction (it counts on no hazard when the buffer offset is a
+                            // scalar register): the granule then carried the NEXT granule's halves
+                            // under valid tags.  Found with a checksum in place of the second tag
+                            // (no granule ever validated); two wait states after every such store.
+                            __builtin_amdgcn_sched_barrier(0);
+                            asm volatile("s_nop 1");
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                 }
             }
