@@ -388,10 +388,13 @@ def run_identity(args, comm, device, dv, use_dist, rank):
 
     perm_rng = np.random.default_rng(1)                   # same stream on every rank
     ev = []
-    nxt = [torch.from_numpy(perm_rng.permutation(p).astype(np.float64)).to(device)]
+    nxt = [perm_rng.permutation(p).astype(np.float64)]
 
-    def draw_next():                                      # on the host while the sweep runs
-        nxt.append(torch.from_numpy(perm_rng.permutation(p).astype(np.float64)).to(device))
+    def draw_next():
+        """On the host while the sweep runs.  The engine uploads the order on a side stream and
+        packs the next sweep's X operands there, beside the running sweep (as locus_core_ does)."""
+        nxt.append(perm_rng.permutation(p).astype(np.float64))
+        return nxt[-1]
 
     def step():                                           # every step sweeps in a fresh random order
         return eng.iterate(nxt.pop(0), 1.0, with_elbo=True, after_launch=draw_next, c_next=1.0)

@@ -177,12 +177,31 @@ typedef struct locus_hip_sweep_args {
     const double* ls2;          /* logit: [p][d] log(sig2_beta_vb) / 2 (locus_hip_half_log_dev),
                                    the last term of src/coreLoop.cpp:125 tabulated outside the
                                    latency-bound sweep; NULL = the kernel takes the logarithm */
+    int32_t prepacked;          /* 1: locus_hip_sweep_prepack_dev has run on this workspace with the
+                                   same n, p, d, shuffled_ind, nsteps and cfg (see there); 0: the
+                                   sweep packs its operands itself */
+    int32_t pad_;
 } locus_hip_sweep_args;
 
 /* One CAVI sweep over the covariates in `shuffled_ind` order; logit = 0 runs the
  * identity-family update, logit = 1 the coreLogitLoop update.  A non-permutation
  * makes the sweep a no-op and is reported by locus_hip_sweep_status_dev(). */
 int locus_hip_sweep_dev(const locus_hip_sweep_args* args, int logit, void* stream);
+
+/* The part of the next sweep that depends only on X and on the order of the covariates, done
+ * ahead of it: the permutation check and the block-packed operand copies of X for every launch
+ * geometry the sweep over d responses will use (identity family, matrix-core sweep: n <= 2016;
+ * otherwise LOCUS_HIP_EUNSUPPORTED and nothing is done -- sweep as usual).  Reads args->n, p, d,
+ * Xp, xtx, shuffled_ind, nsteps, cfg, workspace (>= locus_hip_sweep_prepack_workspace_bytes(n, p,
+ * d): the geometries lie side by side); lo, l1, R, state and the per-response constants are not
+ * touched, so this can run on another stream while the current sweep -- on ANOTHER workspace --
+ * and the iteration's reductions are still in flight (the drivers do: ~3 % of a C3 iteration,
+ * ~7 % at C2).  The sweep proper is then locus_hip_sweep_dev with args->prepacked = 1 on the same
+ * workspace, ordered after this call.  NO COUNTERPART IN THE REFERENCE (src/coreLoop.cpp:36-52 reads
+ * X in place). */
+int locus_hip_sweep_prepack_dev(const locus_hip_sweep_args* args, void* stream);
+/* Bytes of workspace for that; 0 when (n, d) is not swept by the matrix-core kernels. */
+int64_t locus_hip_sweep_prepack_workspace_bytes(int64_t n, int64_t p, int64_t d);
 
 /* Synchronises `stream` and returns 0, LOCUS_HIP_EPERM if the last sweep that used
  * `workspace` (sized for p covariates) was given an invalid shuffled_ind (that sweep was a

@@ -36,6 +36,7 @@ class SweepArgs(ctypes.Structure):
         ("workspace", _ptr), ("workspace_bytes", _i64), ("nsteps", _i64),
         ("cfg", ctypes.c_int32 * 4),
         ("ls2", _ptr),
+        ("prepacked", ctypes.c_int32), ("pad_", ctypes.c_int32),
     ]
 
 
@@ -78,6 +79,8 @@ SIGNATURES = {
     "locus_hip_pack_x_dev": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr]),
     "locus_hip_sweep_workspace_bytes": (_i64, [_i64, _i64]),
     "locus_hip_sweep_dev": (_int, [ctypes.POINTER(SweepArgs), _int, _ptr]),
+    "locus_hip_sweep_prepack_dev": (_int, [ctypes.POINTER(SweepArgs), _ptr]),
+    "locus_hip_sweep_prepack_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "locus_hip_sweep_status_dev": (_int, [_ptr, _i64, _ptr]),
     "locus_hip_sweep_static_dev": (_int, [ctypes.POINTER(SweepArgs), _int, _ptr]),
     "locus_hip_sweep_config": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int32)]),

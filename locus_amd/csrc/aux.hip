@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) build_steps_kernel(const double* __restri
             atomicOr(err, 2);
         }
         s.j = j;
-        s.lod = l1[j] - lo[j];
+        s.lod = (lo != nullptr) ? l1[j] - lo[j] : 0.0;   // packing ahead: the log-odds come later
         s.xtx = xtx[j];
     }
     steps[i] = s;

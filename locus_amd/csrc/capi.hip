@@ -171,19 +171,23 @@ int static_scratch_ptr(void** out)
     return 0;
 }
 
-int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
+// mode 0: a whole sweep; 1: pack the operands of the sweep that will visit `shuffled_ind`
+// (locus_hip_sweep_prepack_dev: only X, the order and the shape are read); 2: the sweep itself on
+// operands packed by mode 1 (args->prepacked).
+int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st, int mode = 0)
 {
     LOCUS_REQUIRE(a != nullptr, "args is NULL");
     int rc = check_dims(a->n, a->p, a->d);
     if (rc) return rc;
-    LOCUS_REQUIRE(a->Xp && a->xtx && a->shuffled_ind && a->lo && a->l1 && a->R && a->state &&
-                      a->workspace,
-                  "sweep: NULL device pointer");
-    if (logit)
-        LOCUS_REQUIRE(a->s2 && a->xwx && a->W2, "sweep: logit needs s2, xwx, W2");
-    else
-        LOCUS_REQUIRE(a->scale && a->hinv && a->cst && a->s2k,
-                      "sweep: identity family needs scale, hinv, cst, s2k");
+    LOCUS_REQUIRE(a->Xp && a->xtx && a->shuffled_ind && a->workspace, "sweep: NULL device pointer");
+    if (mode != 1) {
+        LOCUS_REQUIRE(a->lo && a->l1 && a->R && a->state, "sweep: NULL device pointer");
+        if (logit)
+            LOCUS_REQUIRE(a->s2 && a->xwx && a->W2, "sweep: logit needs s2, xwx, W2");
+        else
+            LOCUS_REQUIRE(a->scale && a->hinv && a->cst && a->s2k,
+                          "sweep: identity family needs scale, hinv, cst, s2k");
+    }
     LOCUS_REQUIRE((size_t)a->workspace_bytes >= workspace_bytes(a->n, a->p),
                   "sweep: workspace too small");
     const int64_t nsteps = (a->nsteps <= 0 || a->nsteps > a->p) ? a->p : a->nsteps;
@@ -202,8 +206,12 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
 
     WsView ws = carve(a->workspace, a->p);
     const int nsteps_pad = (int)((nsteps + 11) / 12 * 12);
-    rc = build_steps(a->shuffled_ind, a->lo, a->l1, a->xtx, ws.steps, ws.visited, ws.err, (int)a->p,
-                     (int)nsteps, (int)step_slots(nsteps), st);
+    if (mode != 0 && (logit || cfg.NPL != -1)) {
+        set_error("sweep: operands are packed ahead for the matrix-core sweep of the identity family only");
+        return LOCUS_HIP_EUNSUPPORTED;
+    }
+    rc = build_steps(a->shuffled_ind, mode == 1 ? nullptr : a->lo, mode == 1 ? nullptr : a->l1, a->xtx,
+                     ws.steps, ws.visited, ws.err, (int)a->p, (int)nsteps, (int)step_slots(nsteps), st);
     if (rc) return rc;
 
     SweepParams prm;
@@ -237,7 +245,10 @@ int sweep_dev(const locus_hip_sweep_args* a, int logit, hipStream_t st)
     }
     if (cfg.NPL < 0) {
         LOCUS_REQUIRE(!logit, "sweep: the matrix-core kernel covers the identity family only");
-        return run_mfma_sweep(prm, cfg, ws.xb, mfma_workspace_bytes(a->n, a->p), st);
+        // (modes 1, 2: the regions of all the plan's geometries follow the small part)
+        const size_t xb_bytes = mode == 0 ? mfma_workspace_bytes(a->n, a->p)
+                                          : (size_t)a->workspace_bytes - small_workspace_bytes(a->p) - 256;
+        return run_mfma_sweep(prm, cfg, ws.xb, xb_bytes, st, mode);
     }
     return launch_sweep(prm, cfg, logit != 0, st);
 }
@@ -593,7 +604,23 @@ int64_t locus_hip_sweep_workspace_bytes(int64_t n, int64_t p)
 
 int locus_hip_sweep_dev(const locus_hip_sweep_args* args, int logit, void* stream)
 {
-    return sweep_dev(args, logit, (hipStream_t)stream);
+    return sweep_dev(args, logit, (hipStream_t)stream, (args != nullptr && args->prepacked) ? 2 : 0);
+}
+
+int locus_hip_sweep_prepack_dev(const locus_hip_sweep_args* args, void* stream)
+{
+    return sweep_dev(args, 0, (hipStream_t)stream, 1);
+}
+
+int64_t locus_hip_sweep_prepack_workspace_bytes(int64_t n, int64_t p, int64_t d)
+{
+    if (n < 1 || p < 1 || d < 1 || n >= (1ll << 31) || d >= (1ll << 31)) return 0;
+    SweepConfig c;
+    if (choose_sweep_config((int)n, (int)d, false, &c) || c.NPL != -1) return 0;
+    const int regions = mfma_plan_regions((int)n, (int)d, c);
+    if (regions <= 0) return 0;
+    const size_t stride = (mfma_workspace_bytes(n, p) + 255) / 256 * 256;
+    return (int64_t)(small_workspace_bytes(p) + 512 + (size_t)regions * stride);
 }
 
 int locus_hip_sweep_static_dev(const locus_hip_sweep_args* args, int logit, void* stream)
@@ -613,6 +640,7 @@ int locus_hip_sweep_static_dev(const locus_hip_sweep_args* args, int logit, void
     void* ptr = nullptr;
     if ((rc = static_scratch_ptr(&ptr))) return rc;
     locus_hip_sweep_args a = *args;
+    a.prepacked = 0;    // (operands packed ahead need a workspace of the caller's, sized for them)
     a.workspace = ptr;  // the device address, never the symbol's name
     a.workspace_bytes = (int64_t)LOCUS_HIP_STATIC_WORKSPACE_BYTES;
     // everything a sweep expects to start from zero (visited[], the error word) is cleared by

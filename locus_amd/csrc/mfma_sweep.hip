@@ -394,7 +394,21 @@ static int cluster_cus() { return std::min(device_cus(), real_cus()); }
 // true when the matrix-core sweep covers n rows (identity family only)
 bool mfma_sweep_covers(int n) { return mfma_kt_for(n, 1) > 0; }
 
-static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, int k_end, bool pack,
+// What a pack_and_launch* call does (bit mask).  A sweep whose operands were packed ahead
+// (locus_hip_sweep_prepack_dev: everything that depends on X and the sweep order only) skips kPack
+// and only refreshes the one thing that depends on the iteration: the log-odds of the steps.
+enum : int { kPack = 1, kLaunch = 2, kRefresh = 4 };
+
+// sc[i * stride] = steps[i].lod: the prior log-odds l1_j - lo_j of every step, in the layout the
+// sweep kernels read (sc4 stride 4, sc2 stride 2)
+__global__ void __launch_bounds__(256) refresh_lod_kernel(const StepRec* __restrict__ steps,
+                                                          double* __restrict__ sc, int stride, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) sc[(size_t)i * stride] = steps[i].lod;
+}
+
+static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, int k_end, int what,
                            void* xb_ws, size_t xb_bytes, hipStream_t st)
 {
     const int MW = mfma_waves(T);
@@ -418,11 +432,17 @@ static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, i
     double* sc4 = axo + (nit + 1) * 256;  // one iteration of slack: staged one block ahead
     int* jidx = reinterpret_cast<int*>(sc4 + nit * 64 + 256);
 
-    if (pack) {
+    if (what & kPack) {
         hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)nit), dim3(256), 0, st, prm.Xp,
                            prm.steps, XS, cgp, axo, sc4, jidx, prm.ld, KT, nblk, MW, prm.d);
         LOCUS_HIP_CHECK(hipGetLastError());
     }
+    if (what & kRefresh) {
+        hipLaunchKernelGGL(refresh_lod_kernel, dim3((unsigned)((16 * nblk + 255) / 256)), dim3(256), 0, st,
+                           prm.steps, sc4, 4, 16 * nblk);
+        LOCUS_HIP_CHECK(hipGetLastError());
+    }
+    if (!(what & kLaunch)) return 0;
 
     MfmaSweepParams mp;
     mp.n = prm.n; mp.p = prm.p; mp.d = prm.d;
@@ -448,7 +468,7 @@ static int pack_and_launch(const SweepParams& prm, int T, int KT, int k_begin, i
 // launches clusters of CS workgroups, at most as many clusters per launch as are resident at once
 // (a cluster's members wait for each other, so every member must be on a CU at the same time).
 static int pack_and_launch1(const SweepParams& prm, int T, int CS, Tiling1 til, int k_begin, int k_end,
-                            bool pack, void* xb_ws, size_t xb_bytes, hipStream_t st)
+                            int what, void* xb_ws, size_t xb_bytes, hipStream_t st)
 {
     const int L = mfma1_lag(CS);
     const int KT = til.KT, ODD = til.ODD;
@@ -481,7 +501,7 @@ static int pack_and_launch1(const SweepParams& prm, int T, int CS, Tiling1 til, 
         set_error("mfma sweep: workspace too small");
         return LOCUS_HIP_EINVAL;
     }
-    if (pack) {
+    if (what & kPack) {
         const size_t lds = sizeof(double) * (size_t)L * 16 * 130 + sizeof(int) * 16 * L;
         if (L == 3) {
             hipLaunchKernelGGL(pack_blocks1_kernel<3>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
@@ -496,6 +516,12 @@ static int pack_and_launch1(const SweepParams& prm, int T, int CS, Tiling1 til, 
         }
         LOCUS_HIP_CHECK(hipGetLastError());
     }
+    if (what & kRefresh) {
+        hipLaunchKernelGGL(refresh_lod_kernel, dim3((unsigned)((16 * nblk + 255) / 256)), dim3(256), 0, st,
+                           prm.steps, sc2, 2, 16 * nblk);
+        LOCUS_HIP_CHECK(hipGetLastError());
+    }
+    if (!(what & kLaunch)) return 0;
     Mfma1Params mp;
     mp.n = prm.n; mp.p = prm.p; mp.d = prm.d;
     mp.nblk = nblk; mp.nsteps = prm.nsteps;
@@ -629,45 +655,47 @@ static Tiling1 explicit_tiling(int G, int n, int CS, int T)
     return G >= 100 ? Tiling1{G - 100, 1} : Tiling1{G, 0};
 }
 
-// cfg: C = T (tiles of 16 responses per cluster; 0 = plan by d), S = workgroups per cluster,
-// G = KT (16-row tiles per matrix wave, 0 = smallest instantiated value that covers n; 100 + KT =
-// waves 3..5 of every workgroup take KT - 1).
-//   C = 1: mfma_sweep1_kernel<KT, S>, S = 1, 2, 3 (0 = chosen from d; anything else = 1);
-//   C = 2: S = 2, 3: mfma_sweep1_kernel<KT, S, 2> (two tiles per cluster);
-//          any other S: mfma_sweep_kernel<2, KT> (two tiles on one workgroup).
-int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
-                   hipStream_t st)
+// One launch of the plan: responses [k_begin, k_end) in one geometry; launches of one geometry
+// share `region`, the slice of the workspace that holds its packed operands.
+struct PlannedLaunch {
+    int T, CS;          // CS = 0: mfma_sweep_kernel<2, KT>
+    Tiling1 til;
+    int k_begin, k_end;
+    int region;
+};
+
+static int make_plan(int n, int d, const SweepConfig& cfg, std::vector<PlannedLaunch>* plan)
 {
+    plan->clear();
     if (cfg.C < 0 || cfg.C > 2) {
         set_error("mfma sweep: bad geometry (T in 0..2)");
         return LOCUS_HIP_EINVAL;
     }
     if (cfg.C == 1) {  // one tile per cluster: mfma_sweep1_kernel, S = workgroups per cluster
         // S = workgroups per cluster (1, 2, 3); 0 = chosen from d; anything else (legacy) = 1
-        const int CS = (cfg.S == 2 || cfg.S == 3) ? cfg.S
-                                                  : (cfg.S == 0 ? choose_cs(prm.n, (prm.d + 15) / 16) : 1);
-        return pack_and_launch1(prm, 1, CS, explicit_tiling(cfg.G, prm.n, CS, 1), 0, prm.d, true, xb_ws,
-                                xb_bytes, st);
+        const int CS = (cfg.S == 2 || cfg.S == 3) ? cfg.S : (cfg.S == 0 ? choose_cs(n, (d + 15) / 16) : 1);
+        plan->push_back({1, CS, explicit_tiling(cfg.G, n, CS, 1), 0, d, 0});
+        return 0;
     }
     if (cfg.C == 2 && cfg.S >= 2 && cfg.S <= 3) {
-        return pack_and_launch1(prm, 2, cfg.S, explicit_tiling(cfg.G, prm.n, cfg.S, 2), 0, prm.d, true,
-                                xb_ws, xb_bytes, st);
+        plan->push_back({2, cfg.S, explicit_tiling(cfg.G, n, cfg.S, 2), 0, d, 0});
+        return 0;
     }
     if (cfg.C != 0) {
-        const int KT = cfg.G > 0 ? cfg.G : mfma_kt_for(prm.n, cfg.C);
-        return pack_and_launch(prm, cfg.C, KT, 0, prm.d, true, xb_ws, xb_bytes, st);
+        plan->push_back({cfg.C, 0, Tiling1{cfg.G > 0 ? cfg.G : mfma_kt_for(n, cfg.C), 0}, 0, d, 0});
+        return 0;
     }
-    if (mfma_kt_for(prm.n, 1) == 0) {
+    if (mfma_kt_for(n, 1) == 0) {
         set_error("mfma sweep: n too large for the matrix-core kernel");
         return LOCUS_HIP_EUNSUPPORTED;
     }
-    const std::vector<LaunchType> types = launch_types(prm.n);
+    const std::vector<LaunchType> types = launch_types(n);
     if (types.empty()) {
         set_error("mfma sweep: no launch geometry for this shape");
         return LOCUS_HIP_EUNSUPPORTED;
     }
     // best[u] = cheapest cover of u units of 16 responses
-    const int U = (prm.d + 15) / 16;
+    const int U = (d + 15) / 16;
     std::vector<double> best((size_t)U + 1, 0.0);
     std::vector<int> pick((size_t)U + 1, -1);
     for (int u = 1; u <= U; ++u) {
@@ -678,19 +706,81 @@ int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, 
             if (v < best[u]) { best[u] = v; pick[u] = (int)t; }
         }
     }
-    int k = 0, last = -1;
+    std::vector<int> region_of(types.size(), -1);
+    int k = 0, nregions = 0;
     for (int u = U; u > 0;) {
         const LaunchType& lt = types[pick[u]];
-        const int take = std::min(prm.d - k, lt.cap);
-        const bool pack = pick[u] != last;  // consecutive launches of one geometry share the operands
-        const int rc = (lt.CS == 0)
-                           ? pack_and_launch(prm, 2, lt.KT, k, k + take, pack, xb_ws, xb_bytes, st)
-                           : pack_and_launch1(prm, lt.T, lt.CS, Tiling1{lt.KT, lt.ODD}, k, k + take, pack,
-                                              xb_ws, xb_bytes, st);
-        if (rc) return rc;
-        last = pick[u];
+        const int take = std::min(d - k, lt.cap);
+        if (region_of[pick[u]] < 0) region_of[pick[u]] = nregions++;
+        plan->push_back({lt.T, lt.CS, Tiling1{lt.KT, lt.ODD}, k, k + take, region_of[pick[u]]});
         k += take;
         u -= std::max(1, lt.cap / 16);
+    }
+    return 0;
+}
+
+static size_t region_stride(int64_t n, int64_t p) { return (mfma_workspace_bytes(n, p) + 255) / 256 * 256; }
+
+// Geometries (= workspace regions of packed operands) in the plan for (n, d): what a workspace
+// must hold for locus_hip_sweep_prepack_dev, which keeps all of them side by side.
+int mfma_plan_regions(int n, int d, const SweepConfig& cfg)
+{
+    std::vector<PlannedLaunch> plan;
+    if (make_plan(n, d, cfg, &plan)) return 0;
+    int r = 0;
+    for (const PlannedLaunch& l : plan) r = std::max(r, l.region + 1);
+    return r;
+}
+
+// cfg: C = T (tiles of 16 responses per cluster; 0 = plan by d), S = workgroups per cluster,
+// G = KT (16-row tiles per matrix wave, 0 = smallest instantiated value that covers n; 100 + KT =
+// waves 3..5 of every workgroup take KT - 1).
+//   C = 1: mfma_sweep1_kernel<KT, S>, S = 1, 2, 3 (0 = chosen from d; anything else = 1);
+//   C = 2: S = 2, 3: mfma_sweep1_kernel<KT, S, 2> (two tiles per cluster);
+//          any other S: mfma_sweep_kernel<2, KT> (two tiles on one workgroup).
+// mode 0: every launch packs its operands into the one region (xb_bytes >= mfma_workspace_bytes)
+//         unless the launch before it used the same geometry, then runs;
+// mode 1: pack only, every geometry into a region of its own (xb_bytes >= regions x that);
+// mode 2: the operands are there (mode 1 with the same n, p, d, sweep order, geometry): refresh
+//         the steps' log-odds, which is all that changes between iterations, and run.
+int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
+                   hipStream_t st, int mode)
+{
+    std::vector<PlannedLaunch> plan;
+    int rc = make_plan(prm.n, prm.d, cfg, &plan);
+    if (rc) return rc;
+    const size_t stride = region_stride(prm.n, prm.p);
+    int nregions = 0;
+    for (const PlannedLaunch& l : plan) nregions = std::max(nregions, l.region + 1);
+    if (mode != 0 && (size_t)nregions * stride > xb_bytes) {
+        set_error("mfma sweep: workspace too small for operands packed ahead (" + std::to_string(nregions) +
+                  " geometries; see locus_hip_sweep_prepack_workspace_bytes)");
+        return LOCUS_HIP_EINVAL;
+    }
+    std::vector<char> touched((size_t)nregions + 1, 0);
+    int last_region = -1;
+    for (const PlannedLaunch& l : plan) {
+        int what;
+        char* base = static_cast<char*>(xb_ws);
+        size_t bytes = xb_bytes;
+        if (mode == 0) {
+            what = kLaunch | (l.region != last_region ? kPack : 0);
+        } else {
+            base += (size_t)l.region * stride;
+            bytes = stride;
+            const bool first = !touched[l.region];
+            touched[l.region] = 1;
+            if (mode == 1) {
+                if (!first) continue;
+                what = kPack;
+            } else {
+                what = kLaunch | (first ? kRefresh : 0);
+            }
+        }
+        rc = (l.CS == 0) ? pack_and_launch(prm, l.T, l.til.KT, l.k_begin, l.k_end, what, base, bytes, st)
+                         : pack_and_launch1(prm, l.T, l.CS, l.til, l.k_begin, l.k_end, what, base, bytes, st);
+        if (rc) return rc;
+        last_region = l.region;
     }
     return 0;
 }

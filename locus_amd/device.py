@@ -72,6 +72,58 @@ class Sweeper:
         self.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         self.cfg = cfg
         self._keep = None
+        self.device = device
+        self._pre = None          # pack-ahead state, allocated by the first prepack()
+
+    # ---- operands of the NEXT sweep packed while the current one runs ------------------------
+    def prepack(self, shuffled_ind_next):
+        """Queue, on a side stream, the part of the next sweep that depends only on X and the
+        sweep order (locus_hip_sweep_prepack_dev) into the workspace the running sweep does NOT
+        use.  `shuffled_ind_next`: the order as a host array (uploaded on the side stream, so
+        that nothing waits for the running sweep) or a device tensor.  identity() given the
+        returned device tensor picks the packed operands up.  Returns None when the shape is not
+        swept by the matrix-core kernels (nothing queued)."""
+        if self.cfg is not None and int(self.cfg[0]) != -1:
+            return None
+        pre = self._pre
+        if pre is None:
+            nb = int(_lib.lib().locus_hip_sweep_prepack_workspace_bytes(self.n, self.p, self.d))
+            if nb <= 0:
+                self._pre = False
+                return None
+            pre = self._pre = dict(
+                ws=[torch.empty((nb,), dtype=torch.uint8, device=self.device) for _ in range(2)],
+                side=torch.cuda.Stream(device=self.device), turn=0, used=[None, None], ready=None)
+        if pre is False:
+            return None
+        main = torch.cuda.current_stream(self.device)
+        slot = pre["turn"]
+        pre["turn"] ^= 1
+        side = pre["side"]
+        if pre["used"][slot] is not None:          # the sweep that last read this workspace
+            side.wait_event(pre["used"][slot])
+        with torch.cuda.stream(side):
+            ind = shuffled_ind_next
+            if not torch.is_tensor(ind):
+                ind = torch.from_numpy(np.ascontiguousarray(ind, dtype=np.float64)).to(self.device)
+            a = _lib.SweepArgs()
+            a.n, a.p, a.d = self.n, self.p, self.d
+            a.Xp, a.xtx = self.px.Xp.data_ptr(), self.px.xtx.data_ptr()
+            a.shuffled_ind = ind.data_ptr()
+            a.workspace, a.workspace_bytes = pre["ws"][slot].data_ptr(), pre["ws"][slot].numel()
+            if self.cfg is not None:
+                for i in range(4):
+                    a.cfg[i] = int(self.cfg[i])
+            rc = _lib.lib().locus_hip_sweep_prepack_dev(ctypes.byref(a), side.cuda_stream)
+            if rc == -2:                           # LOCUS_HIP_EUNSUPPORTED: sweep as usual
+                self._pre = False
+                return None
+            _lib.check(rc)
+            done = torch.cuda.Event()
+            done.record(side)
+        ind.record_stream(main)
+        pre["ready"] = (ind, slot, done)
+        return ind
 
     def _args(self, shuffled_ind, lo, l1, R, state, stats, nsteps=0):
         a = _lib.SweepArgs()
@@ -95,6 +147,22 @@ class Sweeper:
                                          s2k.data_ptr())
         a.cfac = float(cfac)
         self._keep = (shuffled_ind, lo, l1, scale, hinv, cst, s2k)
+        pre = self._pre if isinstance(self._pre, dict) else None
+        self._status_ws = self.workspace
+        if pre is not None and pre["ready"] is not None:
+            ind, slot, done = pre["ready"]
+            pre["ready"] = None
+            if ind is shuffled_ind and nsteps == 0:      # the order these operands were packed for
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(done)
+                a.workspace, a.workspace_bytes = pre["ws"][slot].data_ptr(), pre["ws"][slot].numel()
+                a.prepacked = 1
+                _lib.check(_lib.lib().locus_hip_sweep_dev(ctypes.byref(a), 0, _stream()))
+                used = torch.cuda.Event()
+                used.record(main)
+                pre["used"][slot] = used
+                self._status_ws = pre["ws"][slot]
+                return
         _lib.check(_lib.lib().locus_hip_sweep_dev(ctypes.byref(a), 0, _stream()))
 
     def logit(self, shuffled_ind, lo, l1, s2, xwx, W2, half_lsi, R, state, stats=None, nsteps=0,
@@ -106,11 +174,14 @@ class Sweeper:
         a.ls2 = ls2.data_ptr() if ls2 is not None else None
         a.half_lsi = float(half_lsi)
         self._keep = (shuffled_ind, lo, l1, s2, xwx, W2, ls2)
+        self._status_ws = self.workspace
         _lib.check(_lib.lib().locus_hip_sweep_dev(ctypes.byref(a), 1, _stream()))
 
     def status(self):
         """Synchronise and raise if the last sweep saw an invalid shuffled_ind."""
-        _lib.check(_lib.lib().locus_hip_sweep_status_dev(_p(self.workspace), self.p, _stream()))
+        ws = getattr(self, "_status_ws", None)
+        _lib.check(_lib.lib().locus_hip_sweep_status_dev(_p(ws if ws is not None else self.workspace),
+                                                         self.p, _stream()))
 
 
 def residual(Y, A, Zmu=None, W2=None, out=None, to_residual=True):

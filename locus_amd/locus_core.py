@@ -565,7 +565,11 @@ class IdentityEngine:
             prm = self.host.commit_iteration(nxt)
         else:
             prm = self.host.begin_iteration(c)
-        ind = shuffled_ind if self.torch.is_tensor(shuffled_ind) else self._up(shuffled_ind)
+        pre, self._pre_ind = getattr(self, "_pre_ind", None), None
+        if pre is not None and pre[0] is shuffled_ind:
+            ind = pre[1]           # uploaded, and its operands packed, while the last sweep ran
+        else:
+            ind = shuffled_ind if self.torch.is_tensor(shuffled_ind) else self._up(shuffled_ind)
         self.sweeper.identity(ind, self._up(prm["lo"]), self._up(prm["l1"]),
                               self._up(prm["scale"]), self._up(prm["hinv"]), self._up(prm["cst"]),
                               self._up(prm["s2k"]), c, self.R, self.state, self.stats)
@@ -583,16 +587,27 @@ class IdentityEngine:
             if c_next is not None:
                 self._prm_next = self.host.prepare_iteration(c_next)
             if after_launch is not None:
-                after_launch()
+                self._pack_ahead(after_launch())
             self.sweeper.status()
             return None if lb is None else float(lb)
         packed = self.torch.cat([self.stats.reshape(-1), tail])
         if after_launch is not None:
-            after_launch()
+            self._pack_ahead(after_launch())
         h = packed.cpu().numpy()
         self.sweeper.status()
         stats = h[:-1].reshape(4, self.d_loc)
         return self.host.end_iteration(stats, rs_gam, float(h[-1]), c, with_elbo)
+
+    def _pack_ahead(self, next_ind):
+        """`after_launch` may return the NEXT iteration's sweep order: whatever of that sweep
+        depends only on X and the order (permutation check, block-packed operands) is then queued
+        on a side stream now, beside the running sweep (Sweeper.prepack).  The caller passes the
+        same object to the next iterate()."""
+        if next_ind is None or not hasattr(self.sweeper, "prepack"):
+            return
+        dev_ind = self.sweeper.prepack(next_ind)
+        if dev_ind is not None:
+            self._pre_ind = (next_ind, dev_ind)
 
     def iterate_scheme(self, scheme, c=1.0, with_elbo=True, c_next=None, k_order=None,
                        j_orders=None):
@@ -782,6 +797,7 @@ def locus_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_vb, tol,
         def draw_next(it=it):                                            # overlaps the sweep
             if it < maxit:
                 nxt[it + 1] = np.ascontiguousarray(perm_fn(it + 1), dtype=np.float64)
+                return nxt[it + 1] if batch == "y" else None             # packed ahead by the engine
         c_next = (float(ladder[it]) if it < len(ladder) else 1.0) if annealing else 1.0
         if batch == "y":
             lb = eng.iterate(ind, c, with_elbo=not annealing, after_launch=draw_next,

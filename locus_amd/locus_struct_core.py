@@ -346,6 +346,7 @@ def locus_struct_core_(Y, X, list_hyper, gam_vb, mu_beta_vb, sig2_beta_vb, tau_v
         def draw_next(it=it):                                            # overlaps the sweep
             if it < maxit:
                 nxt[it + 1] = np.ascontiguousarray(perm_fn(it + 1), dtype=np.float64)
+                return nxt[it + 1]                                       # packed ahead by the engine
         lb_new = eng.iterate(ind, 1.0, after_launch=draw_next,
                              **(dict(c_next=1.0 if it < maxit else None) if fused else {}))
         if trace is not None:

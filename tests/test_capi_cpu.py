@@ -32,7 +32,8 @@ def test_header_symbols_exported_and_bound():
 def test_sweep_args_struct_matches_header():
     from locus_amd import _lib
     # 3 int64 + 5 ptr + 4 ptr + double + 3 ptr + double + 3 ptr + ptr + 2 int64 + 4 int32 + ptr
-    assert ctypes.sizeof(_lib.SweepArgs) == 8 * (3 + 5 + 4 + 1 + 3 + 1 + 3 + 1 + 2) + 16 + 8
+    # + 2 int32 (prepacked, pad_)
+    assert ctypes.sizeof(_lib.SweepArgs) == 8 * (3 + 5 + 4 + 1 + 3 + 1 + 3 + 1 + 2) + 16 + 8 + 8
 
 
 def test_tail_args_struct_matches_header():

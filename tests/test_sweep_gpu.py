@@ -374,6 +374,60 @@ def test_wide_vector_geometries(oracle, hip, geom, monkeypatch):
     assert_parity(got, ref, what=f"identity wide geom {geom}")
 
 
+@pytest.mark.parametrize("shape,cus", [((300, 200, 70), None), ((300, 70, 150), "2"), ((130, 40, 5), None)])
+def test_operands_packed_ahead(hip, shape, cus, monkeypatch):
+    """locus_hip_sweep_prepack_dev + locus_hip_sweep_dev(prepacked = 1), as Sweeper.prepack queues
+    them on a side stream while another sweep runs: three sweeps in a row with the next one's
+    operands packed ahead are bit-identical to three plain sweeps, also when the plan has several
+    launch geometries side by side in the workspace (2 pretended CUs: d = 150 -> 64 + 64 + 22) and
+    when the order finally swept is not the one that was packed for (the sweep packs itself)."""
+    import torch
+    from locus_amd import device as dv
+    monkeypatch.delenv("LOCUS_HIP_SWEEP_CFG", raising=False)
+    if cus:
+        monkeypatch.setenv("LOCUS_HIP_MFMA_CUS", cus)
+    n, p, d = shape
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(12)
+    X = rng.normal(size=(n, p))
+    X = np.asfortranarray((X - X.mean(axis=0)) / X.std(axis=0, ddof=1))
+    px = dv.PackedX(dv.to_device_colmajor(X, dev))
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+    gam, mu = rng.random((p, d)) ** 4, rng.normal(scale=0.3, size=(p, d))
+    R0 = rng.normal(size=(d, n))
+    los = [up(np.full(p, -3.0) + rng.normal(scale=0.1, size=p)) for _ in range(3)]
+    l1 = up(np.full(p, -0.05))
+    tau = rng.gamma(2.0, 1.0, size=d)
+    s2 = 1.0 / ((n - 1 + 0.7) * tau)
+    cons = [up(s2 * tau), up(1 / (2 * s2)), up(-(np.log(tau) + np.log(0.7) + np.log(s2)) / 2), up(s2)]
+    perms = [rng.permutation(p).astype(np.float64) for _ in range(4)]
+
+    def run(ahead):
+        state = torch.empty((3, p, d), dtype=torch.float64, device=dev)
+        state[0], state[1] = up(gam), up(mu)
+        state[2] = state[0] * state[1]
+        R = up(R0).t()
+        stats = torch.empty((4, d), dtype=torch.float64, device=dev)
+        sw = dv.Sweeper(px, d, dev)
+        nxt = None
+        for i in range(3):
+            ind = nxt if nxt is not None else up(perms[i])
+            sw.identity(ind, los[i], l1, *cons, 1.0, R, state, stats)
+            nxt = None
+            if ahead and i < 2:
+                # i = 0: pack for the order swept next; i = 1: pack for ANOTHER order (perms[3])
+                got = sw.prepack(perms[i + 1] if i == 0 else perms[3])
+                assert got is not None
+                nxt = got if i == 0 else None
+            sw.status()
+        return state.cpu().numpy(), R.cpu().numpy(), stats.cpu().numpy()
+
+    plain, ahead = run(False), run(True)
+    for a, b in zip(plain, ahead):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(plain[0][0], gam)
+
+
 @pytest.mark.parametrize("vector", [False, True, "stream"])
 def test_partial_sweeps_compose(hip, vector, monkeypatch):
     """nsteps < p (locus_hip_sweep_args.nsteps): visiting the first k covariates of the order and
