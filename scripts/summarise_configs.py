@@ -5,7 +5,8 @@ import csv, glob, json, os, shutil, sys
 
 tag, cfgs = sys.argv[1], sys.argv[2:]
 SHAPES = dict(c2=(1000, 20000, 1000), c4=(2000, 20000, 500), c5=(1000, 50000, 2000))
-SWEEP = ("sweep_kernel", "sweep1_kernel", "pack_blocks", "build_steps_kernel", "logit_la_kernel")
+SWEEP = ("sweep_kernel", "sweep1_kernel", "pack_blocks", "build_steps_kernel", "logit_la_kernel",
+         "refresh_lod_kernel")
 path = f"profiles/traffic_{tag}.json"
 traffic = json.load(open(path)) if os.path.exists(path) else []
 traffic = [t for t in traffic if t.get("config") not in cfgs]
@@ -28,6 +29,10 @@ for cfg in cfgs:
     fetch, write = counter(src, "fetch", "FETCH_SIZE"), counter(src, "write", "WRITE_SIZE")
     n, p, d = SHAPES[cfg]
     nsweeps = max([len(v) for k, v in fetch.items() if "build_steps_kernel" in k] + [1])
+    if any("refresh_lod_kernel" in k for k in fetch):
+        # operands packed ahead (round 3): build_steps runs in the pack-ahead call AND in the sweep;
+        # k sweeps = 1 (first, plain) + 2 (k - 1) + 1 (the last pack-ahead, never swept) = 2 k dispatches
+        nsweeps = max(1, nsweeps // 2)
     seq = [k for k in fetch if any(s in k for s in SWEEP)]
     # median dispatch of every kernel x its dispatches per sweep: the first dispatches of a
     # process read cold (up to 6x the steady-state misses) and would dominate a mean over 4 sweeps

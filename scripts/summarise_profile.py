@@ -25,7 +25,12 @@ lines = ["# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py 
 traffic = []
 # one sweep = the kernels locus_hip_sweep_dev launches; build_steps_kernel runs once per sweep
 nsweeps = max([len(v) for k, v in fetch.items() if "build_steps_kernel" in k] + [1])
-SWEEP = ("sweep_kernel", "sweep1_kernel", "pack_blocks", "build_steps_kernel", "logit_la_kernel")
+if any("refresh_lod_kernel" in k for k in fetch):
+    # operands packed ahead (round 3): build_steps runs in the pack-ahead call AND in the sweep;
+    # k sweeps = 1 (first, plain) + 2 (k - 1) + 1 (the last pack-ahead, never swept) = 2 k dispatches
+    nsweeps = max(1, nsweeps // 2)
+SWEEP = ("sweep_kernel", "sweep1_kernel", "pack_blocks", "build_steps_kernel", "logit_la_kernel",
+         "refresh_lod_kernel")
 seq = [k for k in fetch if any(s in k for s in SWEEP)]
 if seq:
     # median dispatch of every kernel x its dispatches per sweep: the first dispatches of a
