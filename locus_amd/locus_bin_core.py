@@ -77,6 +77,32 @@ class BinHost(HostBase):
         self.rs_m2_alpha = sc[1:1 + self.q].copy()
         return sc[1 + self.q:-1]
 
+    def exchange_t(self, rs_gam_local, tail_t):
+        """exchange() with the scalars as a device tensor [sum(m2_beta) | rowSums(m2_alpha) (q) |
+        extra ...] and nothing brought back: returns the all-reduced tail, on the device."""
+        import torch
+        self._on_device(rs_gam_local.device)
+        if self.comm.solo:
+            self.rs_gam_t = rs_gam_local.reshape(-1)
+            return tail_t
+        buf = torch.cat([rs_gam_local.reshape(-1), tail_t.reshape(-1)])
+        self.comm.all_reduce_sum_(buf)
+        self.rs_gam_t = buf[: self.p]
+        return buf[self.p:]
+
+    def cov_t(self):
+        """The covariate-wise terms of e_beta_gamma_bin_ (R/elbo.R:81-83) and e_omega_ (:114-118)
+        as ONE device scalar, from the all-reduced rowSums(gam_vb)."""
+        import torch
+        d = self.d
+        rs, a, b = self.rs_gam_t, self.a_t, self.b_t
+        a_vb, b_vb = a + rs, b - rs + d                                   # update_a_vb / update_b_vb
+        dg = torch.digamma(a_vb + b_vb)
+        log_om_vb, log_1_min_om_vb = torch.digamma(a_vb) - dg, torch.digamma(b_vb) - dg
+        return ((rs * log_om_vb).sum() + ((d - rs) * log_1_min_om_vb).sum()
+                + ((a - a_vb) * log_om_vb + (b - b_vb) * log_1_min_om_vb + torch.lgamma(a_vb)
+                   + torch.lgamma(b_vb) - torch.lgamma(a_vb + b_vb)).sum() - self.lbeta_ab_t)
+
     def begin_iteration(self):
         """logistic_core.R:55-77 / probit_core.R:51-74 (the parts common to both links)."""
         import torch
@@ -90,19 +116,12 @@ class BinHost(HostBase):
                     lo=torch.digamma(self.a_t + rs) - self.digam_sum_t,                 # R/update_vb.R:187
                     l1=torch.digamma(self.b_t - rs + self.d) - self.digam_sum_t)        # :190
 
-    def finish_elbo(self, loc_sum, e_alpha_fn):
+    def finish_elbo(self, loc_sum, e_alpha_fn, cov=None):
         """Replicated part of elbo_logit_ / elbo_probit_ (logistic_core.R:276-301,
-        probit_core.R:262-286); loc_sum = all-reduced shard-local sums."""
-        import torch
-        d = self.d
-        rs, a, b = self.rs_gam_t, self.a_t, self.b_t
-        a_vb, b_vb = a + rs, b - rs + d                                   # update_a_vb / update_b_vb
-        dg = torch.digamma(a_vb + b_vb)
-        log_om_vb, log_1_min_om_vb = torch.digamma(a_vb) - dg, torch.digamma(b_vb) - dg
-        # covariate terms of e_beta_gamma_bin_ (R/elbo.R:81-83) and e_omega_ (:114-118): one scalar
-        cov = float(((rs * log_om_vb).sum() + ((d - rs) * log_1_min_om_vb).sum()
-                     + ((a - a_vb) * log_om_vb + (b - b_vb) * log_1_min_om_vb + torch.lgamma(a_vb)
-                        + torch.lgamma(b_vb) - torch.lgamma(a_vb + b_vb)).sum() - self.lbeta_ab_t))
+        probit_core.R:262-286); loc_sum = all-reduced shard-local sums; cov = cov_t() already on
+        the host (it travels with the iteration's one read-back), else fetched here."""
+        if cov is None:
+            cov = float(self.cov_t())
         lambda_vb = U.update_lambda_vb_(self.lam, self.sum_gam)
         nu_vb = U.update_nu_bin_vb_(self.nu, self.sum_m2)
         xi_vb = U.update_xi_bin_vb_(self.xi, self.rs_m2_alpha)
@@ -253,23 +272,33 @@ class BinEngine:
         else:
             zs = self._up((self.Z_host ** 2) @ self.s2a_vec)
             dv.probit_w(self.Y, self.M, self.Zmu, self.Q, zs, self.W, self.ey, n, d)
-        sums = t.cat([rows[1:].sum(dim=1), self.ey.sum().reshape(1)]).cpu().numpy()
-        self.sweeper.status()
-        ent, gls, sum_m2, ey = (float(v) for v in sums)
-        self._ey_fit = ey
-        rs_m2a, sum_log_s2a = self._m2_alpha_rows()
-        rs_gam_loc_sum = float(rows[0].sum().item())
+        # Everything the host needs from this iteration in ONE read-back (round 3; it took seven
+        # synchronisations, the GPU idle in between): the shard-local sums are formed, exchanged and
+        # turned into the covariate-wise ELBO terms on the device.
+        sums = rows[1:].sum(dim=1)                                   # ent, gls, sum_m2 (local)
+        ey = self.ey.sum()
+        if self.link == "logit":                                     # update_m2_alpha_, R/update_vb.R:18-29
+            rs_m2a = (self.s2a + self.alpha ** 2).sum(dim=1)
+            sum_log_s2a = t.log(self.s2a).sum().reshape(1)
+        else:
+            rs_m2a = (self.alpha ** 2).sum(dim=1) + self._up(self.s2a_vec) * d
+            sum_log_s2a = t.zeros(1, dtype=t.float64, device=self.device)
         # shard-local sums of the ELBO: e_y_*, and of e_beta_gamma_bin_ the terms
         # gam (log sig2_beta + 1) / 2 and the entropy (R/elbo.R:84-85)
-        loc = ey + (gls + rs_gam_loc_sum) / 2 - ent
-        tot = host.exchange(rows[0], sum_m2, rs_m2a, [loc, sum_log_s2a])
+        loc = ey + (sums[1] + rows[0].sum()) / 2 - sums[0]
+        tot = host.exchange_t(rows[0], t.cat([sums[2].reshape(1), rs_m2a, loc.reshape(1), sum_log_s2a]))
+        h = t.cat([tot, host.rs_gam_t.sum().reshape(1), host.cov_t().reshape(1), ey.reshape(1)]).cpu().numpy()
+        self.sweeper.status()
+        host.sum_m2, host.rs_m2_alpha = float(h[0]), h[1:1 + q].copy()
+        loc_sum, sum_log_s2a_all = float(h[1 + q]), float(h[2 + q])
+        host.sum_gam, cov, self._ey_fit = float(h[3 + q]), float(h[4 + q]), float(h[5 + q])
         if self.link == "logit":
-            fn = lambda lz: E.e_alpha_logit_(host.rs_m2_alpha, float(tot[1]), q, host.d, lz,  # noqa: E731
+            fn = lambda lz: E.e_alpha_logit_(host.rs_m2_alpha, sum_log_s2a_all, q, host.d, lz,  # noqa: E731
                                              host.zeta2_inv_vb)
         else:
             fn = lambda lz: E.e_alpha_probit_(host.rs_m2_alpha, self.s2a_vec, q, host.d, lz,  # noqa: E731
                                               host.zeta2_inv_vb)
-        return host.finish_elbo(float(tot[0]), fn)
+        return host.finish_elbo(loc_sum, fn, cov=cov)
 
     def held_out_elbo(self, lb_fit, Y_test_loc, X_test, Z_test):
         """elbo_probit_ on held-out rows (R/cross_validate.R:345-361).  Of its six terms only
