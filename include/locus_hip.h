@@ -219,7 +219,7 @@ int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream);
  * process).  Calls no hipMalloc / hipFree or allocating routine.  Limits: returns
  * LOCUS_HIP_EUNSUPPORTED when locus_hip_sweep_workspace_bytes(n, p) exceeds the array.  For
  * n <= 2016 that size covers the block-packed X operands and exchange buffers of the matrix-core
- * sweep whatever the family: p <= 7248 at n = 200, 2528 at n = 1000, 1360 at n = 2000; above 2016
+ * sweep whatever the family: p <= 4768 at n = 200, 1648 at n = 1000, 880 at n = 2000; above 2016
  * rows only ~28 p bytes are needed (p up to ~2.3 million).  All calls on one GPU share that GPU's array:
  * two such sweeps that overlap on one GPU (different streams or threads) race -- serialise them.
  * Set-up: the first use on a device looks the array's address up (hipGetSymbolAddress; the HIP
