@@ -228,6 +228,14 @@ int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream);
 #define LOCUS_HIP_STATIC_WORKSPACE_BYTES (64ll << 20)
 int locus_hip_sweep_static_dev(const locus_hip_sweep_args* args, int logit, void* stream);
 
+/* The launches the matrix-core sweep of the identity family makes for d responses of n rows on the
+ * current device: up to max_rows rows of 8 ints {T = tiles of 16
+ * responses per cluster, CS = workgroups per cluster (0: the 32-responses-per-workgroup kernel),
+ * KT, ODD = row tiling, k_begin, k_end = responses [k_begin, k_end), region = which packed operand
+ * set, capacity = responses one such launch can take}.  Returns the number of launches (0: this
+ * shape is not swept by those kernels) or a negative error.  Introspection only. */
+int locus_hip_sweep_plan(int64_t n, int64_t d, int32_t* rows, int max_rows);
+
 /* Geometry the library would pick for (n, d): fills cfg[4] = NPL, C, S, G
  * ({-1, 0, 0, 0}: the matrix-core sweep, launches planned from d; {-3, 0, 0, 0}: the logit
  * look-ahead kernel, responses per workgroup and rows per lane set at launch; {-2, 0, 0, 0}: the

@@ -80,6 +80,7 @@ SIGNATURES = {
     "locus_hip_sweep_workspace_bytes": (_i64, [_i64, _i64]),
     "locus_hip_sweep_dev": (_int, [ctypes.POINTER(SweepArgs), _int, _ptr]),
     "locus_hip_sweep_prepack_dev": (_int, [ctypes.POINTER(SweepArgs), _ptr]),
+    "locus_hip_sweep_plan": (_int, [_i64, _i64, ctypes.POINTER(ctypes.c_int32), _int]),
     "locus_hip_sweep_prepack_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "locus_hip_sweep_status_dev": (_int, [_ptr, _i64, _ptr]),
     "locus_hip_sweep_static_dev": (_int, [ctypes.POINTER(SweepArgs), _int, _ptr]),

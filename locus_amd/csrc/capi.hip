@@ -665,6 +665,18 @@ int locus_hip_sweep_status_dev(const void* workspace, int64_t p, void* stream)
     return decode_sweep_error(herr);
 }
 
+int locus_hip_sweep_plan(int64_t n, int64_t d, int32_t* rows, int max_rows)
+{
+    LOCUS_REQUIRE(rows != nullptr && max_rows >= 1 && n >= 1 && d >= 1 && n < (1ll << 31) && d < (1ll << 31),
+                  "sweep_plan: bad arguments");
+    SweepConfig c;
+    int rc = choose_sweep_config((int)n, (int)d, false, &c);
+    if (rc) return rc;
+    if (c.NPL != -1) return 0;  // not swept by the matrix-core kernels: no plan
+    const int got = mfma_plan_rows((int)n, (int)d, c, rows, max_rows);
+    return got < 0 ? LOCUS_HIP_EUNSUPPORTED : got;
+}
+
 int locus_hip_sweep_config(int64_t n, int64_t d, int logit, int32_t* cfg)
 {
     LOCUS_REQUIRE(cfg != nullptr, "sweep_config: NULL cfg");

@@ -92,6 +92,7 @@ bool mfma_sweep_covers(int n);
 int run_mfma_sweep(const SweepParams& prm, const SweepConfig& cfg, void* xb_ws, size_t xb_bytes,
                    hipStream_t st, int mode = 0);
 int mfma_plan_regions(int n, int d, const SweepConfig& cfg);
+int mfma_plan_rows(int n, int d, const SweepConfig& cfg, int32_t* out, int max_rows);
 int launch_sweep(const SweepParams& prm, const SweepConfig& cfg, bool logit, hipStream_t stream);
 // NPL == -2 selects the streaming kernel (stream_sweep.hip): any n, both families; what the
 // chooser falls back to when n exceeds the register-resident kernels.

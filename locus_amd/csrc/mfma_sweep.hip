@@ -719,6 +719,24 @@ static int make_plan(int n, int d, const SweepConfig& cfg, std::vector<PlannedLa
     return 0;
 }
 
+// The plan as rows {T, CS, KT, ODD, k_begin, k_end, region, capacity} (introspection, tests)
+int mfma_plan_rows(int n, int d, const SweepConfig& cfg, int32_t* out, int max_rows)
+{
+    std::vector<PlannedLaunch> plan;
+    if (make_plan(n, d, cfg, &plan)) return -1;
+    const int cus = device_cus(), ccus = cluster_cus();
+    int r = 0;
+    for (const PlannedLaunch& l : plan) {
+        if (r >= max_rows) break;
+        const int cap = (l.CS == 0) ? 32 * cus
+                                    : 16 * l.T * ((l.CS == 1) ? cus : (ccus / (8 * l.CS)) * 8);
+        const int32_t row[8] = {l.T, l.CS, l.til.KT, l.til.ODD, l.k_begin, l.k_end, l.region, cap};
+        for (int i = 0; i < 8; ++i) out[8 * r + i] = row[i];
+        ++r;
+    }
+    return (int)plan.size();
+}
+
 static size_t region_stride(int64_t n, int64_t p) { return (mfma_workspace_bytes(n, p) + 255) / 256 * 256; }
 
 // Geometries (= workspace regions of packed operands) in the plan for (n, d): what a workspace

@@ -157,6 +157,42 @@ def _top_level_args(text, start):
         i += 1
 
 
+@pytest.mark.parametrize("n", [100, 200, 384, 500, 769, 1000, 1153, 2016])
+@pytest.mark.parametrize("cus", ["1", "2", "37", "256", "304"])
+def test_launch_plan_covers_every_response_once(n, cus, monkeypatch):
+    """The launch plan of the matrix-core sweep is a host-side dynamic
+    programme: whatever d and CU count, its launches must tile [0, d) without gap or overlap, stay
+    within their capacity, use a row tiling that covers n, and share a packed-operand region only
+    between launches of one geometry.  (No GPU needed: without one the library assumes 256 CUs.)"""
+    import ctypes as C
+    from locus_amd import _lib
+    monkeypatch.delenv("LOCUS_HIP_SWEEP_CFG", raising=False)
+    monkeypatch.delenv("LOCUS_HIP_MFMA_PLAN", raising=False)
+    monkeypatch.delenv("LOCUS_HIP_MFMA_CS", raising=False)
+    monkeypatch.setenv("LOCUS_HIP_MFMA_CUS", cus)
+    lib = _lib.lib()
+    rows = (C.c_int32 * (8 * 4096))()
+    ds = sorted(set(list(range(1, 70)) + [127, 128, 129, 1000, 1250, 1280, 1281, 2000, 2500, 2560,
+                                          2561, 4096, 5000, 8192, 8193, 10000, 16385, 40000]))
+    for d in ds:
+        k = lib.locus_hip_sweep_plan(n, d, rows, 4096)
+        assert 1 <= k <= 4096, (n, d, cus, k)
+        pos, geom_of_region = 0, {}
+        for r in range(k):
+            T, CS, KT, ODD, k0, k1, region, cap = rows[8 * r: 8 * r + 8]
+            assert k0 == pos and k0 < k1 <= d, (n, d, cus, r, k0, k1, pos)
+            assert k1 - k0 <= cap, (n, d, cus, r, k1 - k0, cap)
+            if CS == 0:
+                assert T == 2 and ODD == 0 and 7 * 16 * KT >= n
+            else:
+                assert (T, CS) in ((1, 1), (1, 2), (1, 3), (2, 2), (2, 3)) and ODD in (0, 1)
+                assert CS * 3 * (2 * KT - ODD) * 16 >= n and KT - ODD >= 1
+            assert geom_of_region.setdefault(region, (T, CS, KT, ODD)) == (T, CS, KT, ODD)
+            pos = k1
+        assert pos == d, (n, d, cus, pos)
+        assert sorted(geom_of_region) == list(range(len(geom_of_region)))
+
+
 def test_rcpp_glue_calls_match_the_header():
     """integration/rcpp/*.cpp cannot be compiled here (no R / Rcpp in the image): at least every
     locus_hip_* call in it must name a declared entry point and pass as many arguments as the
