@@ -75,7 +75,28 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // Tile order.  Default: the launch order (x fastest).  LOCUS_HIP_GEMM_XCD=1 gives every XCD
+    // (workgroups go to the 8 XCDs round-robin by linear id) a contiguous eighth of the tile
+    // list with the short grid dimension fastest, so that the workgroups of one XCD share few
+    // strips of the long operand side.  Measured on MI355X (scripts/gemm_traffic.sh, round 3):
+    // it does NOT pay -- the C3 init product reads 58.6 GB through the L2s instead of 40.8 GB and
+    // takes 17.8 ms instead of 17.4; the X^2 products of C4 read 0.92 GB instead of 2.63 GB for
+    // the same time.  Workgroups that share a strip are dispatched as earlier ones retire, so
+    // after the first wave they sit at unrelated k and a 4 MB L2 holds no strip long enough to
+    // be hit twice, whatever the order; the kernel is not bound by that traffic either (the
+    // time follows SQ_VALU_MFMA_BUSY: 84 % at the 2.09 GHz the chip sustains under this load).
+    int bx, by;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int lin = blockIdx.x + gx * blockIdx.y, tiles = gx * gy;
+        const int xcd = lin & 7, slot = lin >> 3;
+        const int q8 = tiles >> 3, rem = tiles & 7;
+        const int tile = !g.xcd_order ? lin : xcd * q8 + (xcd < rem ? xcd : rem) + slot;
+        if (!g.xcd_order) { bx = blockIdx.x; by = blockIdx.y; }
+        else if (gx <= gy) { bx = tile % gx; by = tile / gx; }
+        else { by = tile % gy; bx = tile / gy; }
+    }
+    const int m0 = bx * BM, n0 = by * BN;
     // split-K: this workgroup's slice of the contraction
     const int kb = g.kchunk ? (int)blockIdx.z * g.kchunk : 0;
     const int kend = g.kchunk ? (kb + g.kchunk < g.k ? kb + g.kchunk : g.k) : g.k;
@@ -293,6 +314,7 @@ int gemm_f64(const GemmDesc& g_in, hipStream_t st)
 {
     if (g_in.m <= 0 || g_in.n <= 0) return 0;
     GemmDesc g = g_in;
+    g.xcd_order = getenv("LOCUS_HIP_GEMM_XCD") ? 1 : 0;
     // Few output tiles and a deep contraction (X beta of coreBatch at C2, Q = X^2 D at C4: one
     // 64 x 64 tile per CU, 20 000 k-steps each): split the contraction over nz workgroups per
     // tile, partial products to a stream-ordered scratch buffer, summed in a fixed order.

@@ -51,6 +51,7 @@ struct GemmDesc {
     // and writes its partial product to C + z * cz
     int kchunk = 0;
     long cz = 0;
+    int xcd_order = 0;  // 1: XCD-contiguous tile order (LOCUS_HIP_GEMM_XCD, measurements only)
 };
 int gemm_f64(const GemmDesc& g, hipStream_t st);
 int identity_tail(const locus_hip_tail_args& a, int phase, hipStream_t st);

@@ -313,12 +313,12 @@ static Tiling1 mfma1_tiling_for(int64_t n, int CS, int T = 1)
 {
     const int kt_even = mfma1_kt_for(n, CS, T);
     if (kt_even == 0) return {0, 0};
-    // odd deal with the same KT: 3 CS (2 KT - 1) tiles.  Measured (n = 1000, p = 50 000, round 3): it
-    // pays where the operand fetch or the matrix work binds -- one workgroup per tile 17.6 -> 16.8
-    // ms, two 11.2 -> 10.5, two tiles on two 19.95 -> 18.9 -- and loses on clusters of three, which
-    // the chain binds (one tile 9.98 -> 10.4 ms, two tiles 13.8 -> 15.4): those keep the even deal.
+    // odd deal with the same KT: 3 CS (2 KT - 1) tiles.  Measured (n = 1000, p = 50 000, round 3): one
+    // workgroup per tile 17.6 -> 16.8 ms, two 11.2 -> 10.0, three 9.67 -> 9.37; two tiles on two
+    // 19.95 -> 18.4, on three 13.8 -> 12.5 (once the short waves' operand ring was cut from 12
+    // pairs to 6: with 12 the odd deal lost, 15.8).
     const char* force = getenv("LOCUS_HIP_MFMA_EVEN");   // "1": always even, "0": odd wherever it fits
-    const bool want_odd = force ? force[0] == '0' : CS <= 2;
+    const bool want_odd = force ? force[0] != '1' : true;
     if (want_odd && kt_even >= 2 && (int64_t)3 * CS * (2 * kt_even - 1) * 16 >= n) return {kt_even, 1};
     return {kt_even, 0};
 }
@@ -593,17 +593,23 @@ static int choose_cs(int n, int tiles)
 // ---------------------------------------------------------------------------
 // Launch plan.  A launch's duration does not depend on how many of its workgroups are busy --
 // every cluster walks the same p covariates -- but on what bounds one block of 16 steps in its
-// geometry.  Microseconds per block, measured on MI355X at n = 1000, p = 50 000 (round 3,
-// scripts/shard_sweeps.sh) and extended linearly in KT, the 16-row tiles per matrix wave:
+// geometry.  Microseconds per block, measured on MI355X at n = 400, 700, 1000, p = 50 000 (round 3,
+// scripts/shard_sweeps.sh, scripts/perf_sweep.py) as a function of kt, the 16-row tiles per matrix
+// wave averaged over a SIMD (KT, or KT - 1/2 with the odd deal):
 //   A  = mfma_sweep_kernel<2, KT>: 32 responses on ONE CU, 7 matrix waves, the chain shares a
 //        SIMD with one of them; matrix-bound: 8.58 at KT = 9                       0.953 KT
-//   one tile of 16 responses on 1, 2, 3 CUs: bound by the operand fetch of the six matrix waves
-//        through the CU's L1: 5.63 at KT = 11 alone (0.512 KT), 3.58 at KT = 6 and 3.35 at
-//        KT = 5.5 (the odd deal) in a cluster of two (0.60 KT)
-//        or by the chain: 2.5 alone, 3.1 with the cluster hand-over (3.17 at CS = 3, KT = 4)
-//   two tiles (32 responses) on 2, 3 CUs: matrix-bound (6.38 at KT = 6, 6.04 at 5.5)  1.10 KT
-//        (on 4 CUs: measured no faster than on 3 -- chain-bound -- and its helper spills: not built)
-//        or by the chain and the helper sharing a SIMD with twice the hand-over: 4.36
+//        or bound by that chain wave (32 responses, next to an MFMA stream): 4.85 at KT = 2,
+//        5.7 at KT = 4 (4.0 + 0.43 KT) -- n = 200, d = 1000 ran here in 6.3 ms until the plan
+//        knew; one tile per CU takes 3.3
+//   one tile of 16 responses on 1, 2, 3 CUs: bound by the matrix waves (their operand fetch
+//        through the CU's L1 and their MFMAs): 5.15 at kt = 10.5 alone (0.49 kt), 3.0 at kt = 5.5
+//        in a cluster of two (0.55 kt);
+//        or by the chain wave: 2.5 - 2.8 alone (2.4 + 0.08 kt), 2.6 in a cluster of two, 2.75 of
+//        three (with the cluster hand-over)
+//   two tiles (32 responses) on 2, 3 CUs: matrix-bound, 5.68 at kt = 5.5 on two (1.04 kt), 3.78 at
+//        kt = 3.5 on three (1.08 kt); or by the chain wave and the helper, which serve two tiles:
+//        3.33 / 3.82 at kt = 1.5 / 2.5 on three, 3.55 at 2.5 on two (3.0 + 0.25 kt)
+//        (on 4 CUs: measured no faster than on 3 and its helper spills: not built)
 // Members of a cluster must all be resident, so a cluster launch takes at most
 // floor(CUs / 8 CS) 8 clusters.  The plan minimises the sum of the launch durations over all ways
 // of covering d responses (dynamic programme over units of 16 responses); every launch of a new
@@ -631,7 +637,7 @@ static std::vector<LaunchType> launch_types(int n)
     }
     const double pack = 0.2;
     if (const int kt = mfma_kt_for(n, 2); kt > 0 && (only_t == 0 || only_t == 1))
-        v.push_back({2, 0, kt, 0, 32 * cus, 0.953 * kt + pack});
+        v.push_back({2, 0, kt, 0, 32 * cus, std::max(0.953 * kt, 4.0 + 0.43 * kt) + pack});
     for (int T = 1; T <= 2; ++T)
         for (int CS = (T == 1 ? 1 : 2); CS <= 3; ++CS) {
             if (only_t != 0 && (T != only_t || CS != only_cs)) continue;
@@ -640,8 +646,9 @@ static std::vector<LaunchType> launch_types(int n)
             const int c = (CS == 1) ? cus : ccus;
             if (til.KT == 0 || (CS > 1 && c < 8 * CS)) continue;
             const int clusters = (CS == 1) ? c : (c / (8 * CS)) * 8;
-            const double chain = (T == 2) ? 4.36 : ((CS == 1) ? 2.5 : 3.1);
-            const double work = (T == 2) ? 1.10 * kt : (CS == 1 ? 0.512 : 0.60) * kt;
+            const double chain = (T == 2) ? 3.0 + 0.25 * kt
+                                          : (CS == 1 ? 2.4 + 0.08 * kt : (CS == 2 ? 2.6 : 2.75));
+            const double work = (T == 2) ? (CS == 2 ? 1.04 : 1.08) * kt : (CS == 1 ? 0.49 : 0.55) * kt;
             v.push_back({T, CS, til.KT, til.ODD, 16 * T * clusters, std::max(work, chain) + pack});
         }
     return v;

@@ -92,14 +92,18 @@ constexpr int ring1_pairs()
 {
     // X operand pairs in flight per matrix wave (must divide 4 KT); the deep tiles keep fewer so
     // that the residual (8 KT registers) and the ring fit 256 registers without spilling
-#ifdef LOCUS_RING1_CAP
+#if defined(LOCUS_RING1_OVR)      // experiments: -D'LOCUS_RING1_OVR(KT,T)=((KT)==3?6:8)'
+    constexpr int cap = LOCUS_RING1_OVR(KT, T);
+#elif defined(LOCUS_RING1_CAP)
     constexpr int cap = LOCUS_RING1_CAP;
 #else
     // (KT <= 4 runs chain-bound with one workgroup per tile: a deeper ring only delays the
     // helper's loads; KT = 5, 6 are bound by the operand fetch, where 12 pairs in flight per wave
     // took the n = 1000 shard from 10.9 to 10.5 ms)
-    // (T = 2 keeps 16 KT residual registers: the ring shrinks as the tile deepens)
-    constexpr int cap = (T == 2) ? (KT <= 4 ? 12 : (KT <= 6 ? 8 : 6)) : ((KT > 14 || KT <= 4) ? 6 : 12);
+    // (T = 2 keeps 16 KT residual registers: the ring shrinks as the tile deepens.  Deeper is not
+    // better: at T = 2, CS = 3, n = 1000 -- KT = 4 and, with the odd deal, 3 -- rings of 8 and 6 pairs
+    // run the d_loc = 2500 shard in 12.5 ms, 8 and 12 in 15.8, 16 and 6 in 13.9, 4 and 6 in 12.8)
+    constexpr int cap = (T == 2) ? (KT <= 6 ? 8 : 6) : ((KT > 14 || KT <= 4) ? 6 : 12);
 #endif
     int best = 1;
     for (int r = 1; r <= cap; ++r)
@@ -461,8 +465,12 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             }
         }
 #ifdef LOCUS_STAMPS
-        if (m == 0) M1STAMP_FLUSH(0);
-        if (m == 5) M1STAMP_FLUSH(1);
+#ifndef LOCUS_STAMP_MA
+#define LOCUS_STAMP_MA 0   // matrix waves whose stamps are kept (roles 0 and 1)
+#define LOCUS_STAMP_MB 5
+#endif
+        if (m == LOCUS_STAMP_MA) M1STAMP_FLUSH(0);
+        if (m == LOCUS_STAMP_MB) M1STAMP_FLUSH(1);
 #endif
 
         __syncthreads();  // E1: everybody is done with `part`
@@ -784,7 +792,13 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             c_s2[tau] = kvalid[tau] ? P.s2k[kh[tau]] : 0.0;
             acc_g[tau] = acc_m2[tau] = acc_b2[tau] = 0.0;
         }
-        const bool storer = (c_mem == 0);
+        // Member 0 leads: it adds up the members' column statistics at the end and writes them.
+        // The rows of gam / mu / beta are written by the members in turn, block bs by member
+        // bs % CS (every member runs the same chain and holds the same results): on one member
+        // these stores -- 24 T scattered stores and ~150 instructions per block, issued in the
+        // gaps the chain wave leaves -- made its helper the slowest wave of the whole cluster
+        // (4080 of 10 290 cycles per block at T = 2, CS = 3, the partners waiting for its granules).
+        const bool leader = (c_mem == 0);
         unsigned long long* xb_tile = nullptr;
         int* xf_tile = nullptr;
         if constexpr (CS > 1) {
@@ -859,10 +873,20 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     // front of the FIRST check as well, because the registers may come from the
                     // refetch: ~1800 cycles per block waiting for the previous block's result stores.)
                     auto tags_ok = [&]() {
-                        bool ok = true;
+                        // every tag equals `tag` <=> their minimum and maximum do.  One v_min3 and one
+                        // v_max3 per granule, vector registers only: as compares, each of them wrote
+                        // a scalar register pair that a scalar AND then waited for -- ~85 cycles per
+                        // granule of dependent latency on this wave (2060 per block at T = 2, CS = 3).
+                        unsigned mn[2] = {tag, tag}, mx[2] = {tag, tag};
 #pragma unroll
-                        for (int e = 0; e < NGV; ++e) ok = ok && (gv[e].x == tag) && (gv[e].w == tag);
-                        return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+                        for (int e = 0; e < NGV; ++e) {
+                            const unsigned a_ = gv[e].x, b_ = gv[e].w;
+                            const unsigned lo_ = a_ < b_ ? a_ : b_, hi_ = a_ < b_ ? b_ : a_;
+                            mn[e & 1] = lo_ < mn[e & 1] ? lo_ : mn[e & 1];
+                            mx[e & 1] = hi_ > mx[e & 1] ? hi_ : mx[e & 1];
+                        }
+                        const bool bad = mn[0] != tag || mn[1] != tag || mx[0] != tag || mx[1] != tag;
+                        return __builtin_amdgcn_ballot_w64(bad) == 0ull;
                     };
                     if (!tags_ok()) {  // a partner is late: poll
                         for (int spin = 0;; ++spin) {
@@ -892,7 +916,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 const xgran v = gv[(cm * T + tau) * 4 + g];
-                                sg[tau][g] += __hiloint2double((int)v.z, (int)v.y);
+                                const double dv = __hiloint2double((int)v.z, (int)v.y);
+                                sg[tau][g] = (cm == 0) ? dv : sg[tau][g] + dv;
                             }
                 }
 #pragma unroll
@@ -1017,7 +1042,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 }
             }
             // ---- results of the block the chain finished last iteration -----------------------
-            if (storer && bs >= 0 && bs < P.nblk && (CS == 1 || lds_peek(&dead) == 0)) {
+            if (bs >= 0 && bs < P.nblk && (CS == 1 || (bs % CS == c_mem && lds_peek(&dead) == 0))) {
                 const double* mp = mg + (bs & 1) * 2 * TB + q * TW + r;
                 const int* jp = jl + (bs & 7) * 16 + q;
 #pragma unroll
@@ -1055,34 +1080,45 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             gfin[256 * tau + 128 + lane] = acc_b2[tau];
         }
         __syncthreads();  // E2: the matrix waves' sums of squares are in `part`
-        double rss[T];
+        // per-response totals of this workgroup: [0] sum of squares of its residual rows, [1..3] the
+        // column statistics of the blocks it stored (four step classes per response, summed here)
+        double tot[T][4];
 #pragma unroll
         for (int tau = 0; tau < T; ++tau) {
-            rss[tau] = 0.0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tot[tau][v] = 0.0;
             if (lane < 16) {
 #pragma unroll
                 for (int ss = 0; ss < MW; ++ss) {
                     const double* pp = part + (ss * T + tau) * 64 + lane;
-                    rss[tau] += (pp[0] + pp[16]) + (pp[32] + pp[48]);
+                    tot[tau][0] += (pp[0] + pp[16]) + (pp[32] + pp[48]);
                 }
+                const double* sp = gfin + 256 * tau + lane;
+#pragma unroll
+                for (int v = 0; v < 3; ++v)
+                    tot[tau][v + 1] = (sp[64 * v] + sp[64 * v + 16]) + (sp[64 * v + 32] + sp[64 * v + 48]);
             }
         }
         if (CS > 1 && alive) {
-            // sum of squares over the members' row slices, added in member order by member 0
+            // the members' totals, added in member order by the leader
             double* rs_base = reinterpret_cast<double*>(xb_tile + (size_t)kXRing * CS * T * 512);
             if (lane < 16) {
 #pragma unroll
                 for (int tau = 0; tau < T; ++tau)
-                    __hip_atomic_store(rs_base + (c_mem * T + tau) * 64 + lane, rss[tau], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        __hip_atomic_store(rs_base + (c_mem * T + tau) * 64 + 16 * v + lane, tot[tau][v],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
                 __hip_atomic_store(xf_tile + c_mem * 32, nit + 1, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-            if (storer) {
+            if (leader) {
 #pragma unroll
-                for (int tau = 0; tau < T; ++tau) rss[tau] = 0.0;
+                for (int tau = 0; tau < T; ++tau)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) tot[tau][v] = 0.0;
 #pragma unroll
                 for (int cm = 0; cm < CS; ++cm) {
                     int spin = 0;
@@ -1097,22 +1133,24 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     if (lane < 16) {
 #pragma unroll
                         for (int tau = 0; tau < T; ++tau)
-                            rss[tau] += __hip_atomic_load(rs_base + (cm * T + tau) * 64 + lane,
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                tot[tau][v] += __hip_atomic_load(
+                                    rs_base + (cm * T + tau) * 64 + 16 * v + lane, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
         }
-        if (alive && P.st != nullptr && storer && lane < 16) {
+        if (alive && P.st != nullptr && leader && lane < 16) {
 #pragma unroll
             for (int tau = 0; tau < T; ++tau)
                 if (kvalid[tau]) {
-                    const double* sp = gfin + 256 * tau + lane;
                     const int k = kh[tau];
-                    P.st[k] = (sp[0] + sp[16]) + (sp[32] + sp[48]);
-                    P.st[(size_t)d + k] = (sp[64] + sp[80]) + (sp[96] + sp[112]);
-                    P.st[2 * (size_t)d + k] = (sp[128] + sp[144]) + (sp[160] + sp[176]);
-                    P.st[3 * (size_t)d + k] = rss[tau];
+                    P.st[k] = tot[tau][1];
+                    P.st[(size_t)d + k] = tot[tau][2];
+                    P.st[2 * (size_t)d + k] = tot[tau][3];
+                    P.st[3 * (size_t)d + k] = tot[tau][0];
                 }
         }
     }

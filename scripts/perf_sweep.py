@@ -81,7 +81,17 @@ def main():
             buf = (ctypes.c_ulonglong * (32 * nwg))()
             fn(buf, 32 * nwg)
             a = np.array(buf, dtype=np.float64).reshape(nwg, 4, 8)
-            a = a[a[:, 2, 1] > 0] / ((nsteps + 15) // 16)
+            member = (np.arange(nwg) >> 3) % cs_used      # c_mem of the kernel (members 8 workgroups apart)
+            keep = a[:, 2, 1] > 0
+            member = member[keep]
+            a = a[keep] / ((nsteps + 15) // 16)
+            if cs_used > 1 and os.environ.get("PERF_BY_MEMBER"):
+                for cm in range(cs_used):
+                    am = a[member == cm]
+                    print(f"   member {cm} ({len(am)} workgroups), medians:")
+                    for ro, nm in ((0, "matrix A"), (1, "matrix B"), (2, "chain"), (3, "helper")):
+                        print(f"      {nm:9s} " + " ".join(f"{v:6.0f}" for v in np.median(am[:, ro, :7], axis=0))
+                              + f"  total={np.median(am[:, ro, :7].sum(axis=1)):.0f}")
             roles = {0: ("matrix wave 0", ["B1-wait", "mfma", "gfin-wait", "corr(l>=2)", "follow+write"]),
                      1: ("matrix wave 5", ["B1-wait", "mfma"]),
                      2: ("chain", ["B1-wait", "run", "-", "next-G"]),
