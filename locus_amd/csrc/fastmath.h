@@ -33,6 +33,30 @@ __device__ __forceinline__ double exp_nonpos(double x)
     return __builtin_ldexp(p, (int)k);
 }
 
+// 2^(j/64), j = 0 .. 63, correctly rounded (scripts/microbench/exp_table_accuracy.c): the table of the
+// chain wave's exponential in mfma_sweep1_kernel.h, copied to LDS once per workgroup.
+//     exp(x) = 2^k 2^(j/64) exp(r),  N = 64 k + j = round(64 x / ln 2),  |r| <= ln 2 / 128,
+// exp(r) - 1 by a degree-5 polynomial (truncation 3.5e-17 relative): 6 instructions after r where
+// the table-free form needs 14.  Max error 1.03 ulp over [-708, 705], 1.56 ulp for the resulting
+// 1 / (1 + exp(a)) against long double on 2e7 points (same file).
+static __device__ const double kExp2Tab64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+
 // The same function with a SHORT dependent path, for the chain wave that runs alone on its SIMD
 // (mfma_sweep1_kernel.h: there every dependent fp64 instruction costs its full ~8 cycle latency):
 // p(r) = 1 + r q(r), q of degree 11 in Estrin form (pairs, then r^2, then r^4) -- 14 instructions,

@@ -175,10 +175,13 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     // (k = response within the cluster, 0 .. 16 T - 1 = 16 tau + r; "D layout" = [tau][g][lane])
     __shared__ __align__(16) double part[2 * MW * TB];   // partial G per matrix wave   [par][m][tau][g][lane]
     __shared__ __align__(16) double gfin[TB];            // reduced G of the next chain block, D layout
-    __shared__ __align__(16) double gx[2 * TB];          // chain starting values       [par][t][k]
+    // chain starting values and beta_old of a block, [par][{gx, beta_old}][t][k]: one array, so that
+    // the chain reads gx and beta_old of a step with ONE ds_read2st64_b64
+    __shared__ __align__(16) double gxbo[4 * TB];
+    double* const gx = gxbo;           // gx of parity par:       gx + par * 2 TB
+    double* const bol = gxbo + TB;     // beta_old of parity par: bol + par * 2 TB
     __shared__ __align__(16) double dl[DR * TB];         // deltas                      [blk & 7][t][k]
     __shared__ __align__(16) double mg[2 * 2 * TB];      // mu, gamma of a chain block  [par][2][t][k]
-    __shared__ __align__(16) double bol[2 * TB];         // beta_old                    [par][t][k]
     __shared__ __align__(16) double gram[2 * 256];       // Gram columns of a chain block [par][t][t2]
     __shared__ __align__(16) double scl[2 * 32];         // lod, xtx of its steps       [par][t][2]
     // CS > 1: A operands of the lag-1 cross-block correction of a block, staged by the helper [par][lane][4]
@@ -193,6 +196,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     // Written by the helper during iteration it as it + 2 and read by every wave behind the
     // barriers of it + 1 and it + 2: all waves see it at the same iteration.
     __shared__ int dead;
+    __shared__ __align__(16) double etab[64];   // 2^(j/64): the chain wave's exponential (fastmath.h)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -213,13 +217,14 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     const size_t pd = (size_t)P.p * d;
 
     for (int e = tid; e < DR * TB; e += 512) dl[e] = 0.0;
-    for (int e = tid; e < 2 * TB; e += 512) { gx[e] = 0.0; bol[e] = 0.0; }
+    for (int e = tid; e < 4 * TB; e += 512) gxbo[e] = 0.0;
     for (int e = tid; e < 4 * TB; e += 512) mg[e] = 0.0;
     for (int e = tid; e < 512; e += 512) gram[e] = 0.0;
     if (tid < 64) scl[tid] = 0.0;
     if (tid < 128) jl[tid] = 0;
     if (tid == 0) { prog = 0; gfin_ready = -1; dead = 0; }
     if (tid < 4) cxf[tid] = -1;
+    if (tid < 64) etab[tid] = kExp2Tab64[tid];
     __syncthreads();
 #ifdef LOCUS_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -458,7 +463,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     }
                 }
                 }
-                double* go = gx + (bx & 1) * 256 + q * 16 + r;
+                double* go = gx + (bx & 1) * 512 + q * 16 + r;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) go[64 * g] = xc[g];
                 M1STAMP(4);
@@ -524,8 +529,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             M1STAMP(0);
             const int b = it - L + 1;  // block whose chain runs now
             if (b >= 0 && b < P.nblk && lane < TW) {
-                const double* gx_l = gx + (b & 1) * TB + lane;
-                const double* bo_l = bol + (b & 1) * TB + lane;
+                const double* gx_l = gx + (b & 1) * 2 * TB + lane;
+                const double* bo_l = bol + (b & 1) * 2 * TB + lane;
                 double* dl_w = dl + (b & (DR - 1)) * TB + lane;
                 double* mg_w = mg + (b & 1) * 2 * TB + lane;
                 const double* sc_b = scl + (b & 1) * 32;      // wave-uniform addresses: broadcast reads
@@ -594,12 +599,19 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     const double a = fma(-cA, dd, cB);                         // coreLoop.cpp:42-46
                     if constexpr (t > 0) delta = fma(-m_p, gam_p, bo_p);       // :48, beta_old - beta_new
                     LOCUS_FENCE();
-                    double x = -fabs(a);
-                    x = (x < -800.0) ? -800.0 : x;  // a select, not fmax: a NaN stays a NaN (fastmath.h)
+                    // gam = 1 / (1 + exp(a)), a clamped to where neither exp nor the reciprocal leaves
+                    // the normal range (gam = 1 below -708, 2e-306 instead of less above 705).  The
+                    // clamp is v_max / v_min, which drop a NaN: `one`, the numerator, carries it
+                    // instead (a NaN log-odds must come out as a NaN gam, src/utils.cpp:3-12).
+                    double x = __builtin_fmax(a, -708.0);
                     if constexpr (t > 0 && t + 1 < kBlk) corr[t + 1] = fma(gp[t + 1], delta, corr[t + 1]);
                     m = c_scale * dot;
                     LOCUS_FENCE();
-                    const double kf = __builtin_rint(x * 1.4426950408889634074);
+                    x = __builtin_fmin(x, 705.0);
+                    const double one = (a == a) ? 1.0 : a;
+                    LOCUS_FENCE();
+                    // N = round(64 x / ln 2) sits in the low word of x (64 / ln 2) + 1.5 2^52
+                    const double kf0 = fma(x, 92.33248261689366, 6755399441055744.0);
                     if constexpr (t > 0) {
                         dl_w[(t - 1) * TW] = delta;
                         mg_w[(t - 1) * TW] = m_p;
@@ -607,62 +619,60 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                         if constexpr (CS == 1 && (t & 3) == 0) lds_publish(&prog, 16 * b + t);
                     }
                     LOCUS_FENCE();
-                    double r = fma(kf, -6.93147180369123816490e-01, x);
+                    const double nf = kf0 - 6755399441055744.0;
+                    const int nn = __double2loint(kf0);
+                    const double tj = etab[nn & 63];                            // 2^(j/64)
                     corr_upd(integral_constant<int, 0>{});
                     corr_upd(integral_constant<int, 1>{});
                     LOCUS_FENCE();
-                    r = fma(kf, -1.90821492927058770002e-10, r);
+                    double r = fma(nf, -6.93147180369123816490e-01 / 64, x);
+                    const int kx = nn >> 6;
                     corr_upd(integral_constant<int, 2>{});
                     corr_upd(integral_constant<int, 3>{});
                     LOCUS_FENCE();
-                    // exp_nonpos_short (fastmath.h), inlined: the Estrin block issues back to back
-                    const double r2 = r * r;
-                    const double q0 = fma(r, 0.5, 1.0);
-                    const double q1 = fma(r, 4.16666666666666666667e-02, 1.66666666666666666667e-01);
-                    const double q2 = fma(r, 1.38888888888888888889e-03, 8.33333333333333333333e-03);
-                    const double q3 = fma(r, 2.48015873015873015873e-05, 1.98412698412698412698e-04);
-                    const double q4 = fma(r, 2.75573192239858906526e-07, 2.75573192239858906526e-06);
-                    const double q5 = fma(r, 2.08767569878680989792e-09, 2.50521083854417187751e-08);
-                    const double r4 = r2 * r2;
-                    const double s0 = fma(q1, r2, q0);
-                    const double s1 = fma(q3, r2, q2);
-                    const double s2 = fma(q5, r2, q4);
-                    const double qq = fma(fma(s2, r4, s1), r4, s0);
-                    const double pp = fma(r, qq, 1.0);
-                    LOCUS_FENCE();
-                    const double e = __builtin_ldexp(pp, (int)kf);
+                    r = fma(nf, -1.90821492927058770002e-10 / 64, r);
                     corr_upd(integral_constant<int, 4>{});
                     corr_upd(integral_constant<int, 5>{});
                     LOCUS_FENCE();
-                    const double den = 1.0 + e;
-                    const double num = (a >= 0.0) ? e : 1.0;
+                    const double r2 = r * r;
+                    const double pa = fma(r, 1.66666666666666666667e-01, 0.5);
+                    const double pb = fma(r, 8.33333333333333333333e-03, 4.16666666666666666667e-02);
                     corr_upd(integral_constant<int, 6>{});
                     LOCUS_FENCE();
-                    // div_1to2 (fastmath.h): the hardware reciprocal (2^-24.4), ONE Newton step and
-                    // the quotient's own correction below -- 0.5 ulp like the two-step form
-                    // (scripts/microbench/div_accuracy.hip), two dependent instructions shorter
-                    double rcp = __builtin_amdgcn_rcp(den);
+                    const double pc = fma(pb, r2, pa);
                     corr_upd(integral_constant<int, 7>{});
                     corr_upd(integral_constant<int, 8>{});
-                    corr_upd(integral_constant<int, 9>{});
                     LOCUS_FENCE();
-                    double tt = fma(-den, rcp, 1.0);
+                    const double pd_ = fma(pc, r2, r);                          // exp(r) - 1
+                    corr_upd(integral_constant<int, 9>{});
                     corr_upd(integral_constant<int, 10>{});
+                    LOCUS_FENCE();
+                    const double pe = fma(tj, pd_, tj);
                     corr_upd(integral_constant<int, 11>{});
-                    corr_upd(integral_constant<int, 12>{});
                     if constexpr (t + 1 < kBlk) base = fma(sc_n.y, bo_n, gx_n);
                     LOCUS_FENCE();
-                    rcp = fma(tt, rcp, rcp);
+                    const double e = __builtin_ldexp(pe, kx);
+                    corr_upd(integral_constant<int, 12>{});
                     corr_upd(integral_constant<int, 13>{});
+                    LOCUS_FENCE();
+                    const double den = 1.0 + e;
                     if constexpr (t + 1 < kBlk) {
                         pre = fma(gc[t + 1], bo_c, corr[t + 1]);
                         gm = gc[t + 1] * m;
                     }
                     LOCUS_FENCE();
-                    const double qv = num * rcp;
+                    // the hardware reciprocal (2^-24.4), ONE Newton step and the quotient's own
+                    // correction: 0.5 ulp (scripts/microbench/div_accuracy.hip)
+                    double rcp = __builtin_amdgcn_rcp(den);
                     if constexpr (t + 1 < kBlk) pre += base;
                     LOCUS_FENCE();
-                    tt = fma(-den, qv, num);
+                    double tt = fma(-den, rcp, 1.0);
+                    LOCUS_FENCE();
+                    rcp = fma(tt, rcp, rcp);
+                    LOCUS_FENCE();
+                    const double qv = one * rcp;
+                    LOCUS_FENCE();
+                    tt = fma(-den, qv, one);
                     LOCUS_FENCE();
                     const double gmv = fma(tt, rcp, qv);
                     LOCUS_FENCE();
@@ -759,7 +769,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                             xc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(axv[c], b4[c][tau], xc[tau],
                                                                            0, 0, 0);
                     // D layout (t = 4 g + q, response 16 tau + r) -> gx[t][k]
-                    double* go = gx + (bx & 1) * TB + q * TW + r;
+                    double* go = gx + (bx & 1) * 2 * TB + q * TW + r;
 #pragma unroll
                     for (int tau = 0; tau < T; ++tau)
 #pragma unroll
@@ -993,7 +1003,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             // for these loads behind the stores would also wait for the stores' write-through).
             __builtin_amdgcn_sched_barrier(0);
             if (bn_blk >= 0 && bn_blk < P.nblk) {
-                double* bp = bol + (bn_blk & 1) * TB + q * TW + r;
+                double* bp = bol + (bn_blk & 1) * 2 * TB + q * TW + r;
 #pragma unroll
                 for (int rd = 0; rd < 4; ++rd)
 #pragma unroll
