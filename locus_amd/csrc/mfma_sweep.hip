@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256)
 pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ steps,
                     double* __restrict__ XS, double* __restrict__ cg, double* __restrict__ ax,
                     double* __restrict__ sc2, int* __restrict__ jidx, int ld, int KT, int nblk, int NW,
-                    int nsteps, int ODD)
+                    int nsteps, int ODD, int NQ)
 {
     extern __shared__ double pk_smem[];
     double (*xt)[130] = reinterpret_cast<double (*)[130]>(pk_smem);               // block b
@@ -50,8 +50,9 @@ pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ s
         const bool act = 16 * b + tid < nsteps;
         const StepRec st = act ? steps[16 * b + tid] : StepRec{0.0, 0.0, 0, 0};
         jidx[16 * b + tid] = st.j;
-        sc2[(size_t)(16 * b + tid) * 2] = st.lod;
-        sc2[(size_t)(16 * b + tid) * 2 + 1] = st.xtx;
+        sc2[(size_t)(16 * b + tid) * 4] = st.lod;
+        sc2[(size_t)(16 * b + tid) * 4 + 1] = st.xtx;
+        sc2[(size_t)(16 * b + tid) * 4 + 3] = 0.0;
     }
     // rows are dealt to the matrix waves in 16-row tiles: per workgroup, waves 0..2 take KT tiles
     // each and waves 3..5 take KT - ODD (mfma_sweep1_kernel.h); the waves' operand streams follow
@@ -150,7 +151,13 @@ pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ s
         for (int w = 0; w < 4; ++w) a += red[((w * L + l) * 4 + (gt >> 2)) * 64 + (gt & 3) * 16 + gs];
         gsum[l] = a;
     }
-    cg[(size_t)b * 256 + gs * 16 + gt] = (gt > gs) ? gsum[0] : 0.0;
+    // Column t = gs of the block's Gram matrix, strictly below the diagonal, in the order the chain
+    // wave's lanes read it (mfma_sweep1_kernel.h): its 64 lanes are NQ = 64 / (16 T) groups that run
+    // the same 16 T responses, group q keeps the corrections of the steps t' = NQ i + q, so entry t'
+    // sits at [t][q = t' % NQ][i = t' / NQ].  The entry right below the diagonal, which every lane
+    // needs, also goes to the step's scalars {lod, xtx, g[t][t+1], 0}.
+    cg[(size_t)b * 256 + gs * 16 + (gt % NQ) * (16 / NQ) + gt / NQ] = (gt > gs) ? gsum[0] : 0.0;
+    if (gt == ((gs + 1) & 15)) sc2[(size_t)(16 * b + gs) * 4 + 2] = (gs < 15) ? gsum[0] : 0.0;
     // (X_b' X_{b-l})[t' = gt][s = gs]: A operand c = gs >> 2 of lane (gs & 3) * 16 + gt
 #pragma unroll
     for (int l = 1; l < L; ++l)
@@ -335,7 +342,7 @@ static size_t mfma1_layout_doubles(int64_t n, size_t nblk, int cus)
     return nit * rows_pad * 32 + 2048      // XS (+ read-ahead slack)
            + nit * 256                     // cg
            + 4 * (nit + 1) * 256           // ax, lags 1..4
-           + 16 * nit * 2 + 256            // sc2
+           + 16 * nit * 4 + 256            // sc2
            + 8 * nit + 256                 // jidx (ints)
            + (size_t)cus * (xbuf_tile_words(2, 2) / 2) + 256   // xbuf: <= cus members in flight
            + (size_t)cus * 16 + 256;       // xflag (32 ints per member)
@@ -400,7 +407,7 @@ bool mfma_sweep_covers(int n) { return mfma_kt_for(n, 1) > 0; }
 enum : int { kPack = 1, kLaunch = 2, kRefresh = 4 };
 
 // sc[i * stride] = steps[i].lod: the prior log-odds l1_j - lo_j of every step, in the layout the
-// sweep kernels read (sc4 stride 4, sc2 stride 2)
+// sweep kernels read (stride 4 in both)
 __global__ void __launch_bounds__(256) refresh_lod_kernel(const StepRec* __restrict__ steps,
                                                           double* __restrict__ sc, int stride, int count)
 {
@@ -492,7 +499,7 @@ static int pack_and_launch1(const SweepParams& prm, int T, int CS, Tiling1 til, 
     double* cgp = XS + xs + 2048;
     double* axp = cgp + nit * 256;
     double* sc2 = axp + 4 * (nit + 1) * 256;
-    int* jidx = reinterpret_cast<int*>(sc2 + 16 * nit * 2 + 256);
+    int* jidx = reinterpret_cast<int*>(sc2 + 16 * nit * 4 + 256);
     unsigned long long* xbuf = reinterpret_cast<unsigned long long*>(jidx) + 8 * nit + 256;
     int* xflag = reinterpret_cast<int*>(xbuf + (size_t)cus * (xbuf_tile_words(2, 2) / 2) + 256);
     const size_t used = (size_t)(reinterpret_cast<char*>(xflag) - static_cast<char*>(xb_ws)) +
@@ -505,20 +512,20 @@ static int pack_and_launch1(const SweepParams& prm, int T, int CS, Tiling1 til, 
         const size_t lds = sizeof(double) * (size_t)L * 16 * 130 + sizeof(int) * 16 * L;
         if (L == 3) {
             hipLaunchKernelGGL(pack_blocks1_kernel<3>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
-                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD);
+                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD, 4 / T);
         } else {
             // 83 KB of dynamic LDS: above the 64 KB default limit.  The attribute belongs to the
             // (function, device) pair, so it is set before every launch (cheap; as in gemm.hip).
             LOCUS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pack_blocks1_kernel<5>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(pack_blocks1_kernel<5>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
-                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD);
+                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD, 4 / T);
         }
         LOCUS_HIP_CHECK(hipGetLastError());
     }
     if (what & kRefresh) {
         hipLaunchKernelGGL(refresh_lod_kernel, dim3((unsigned)((16 * nblk + 255) / 256)), dim3(256), 0, st,
-                           prm.steps, sc2, 2, 16 * nblk);
+                           prm.steps, sc2, 4, 16 * nblk);
         LOCUS_HIP_CHECK(hipGetLastError());
     }
     if (!(what & kLaunch)) return 0;

@@ -52,9 +52,11 @@ struct Mfma1Params {
                           // partner timed out -- the members stop at the next block, store
                           // nothing from then on and leave R as it was before the sweep
     const double* XS;     // [CS * 6][nit][8 KT][64] operand streams (pack_blocks_kernel), nit = nblk + L
-    const double* cg;     // [nit][16][16]  cg[b][t][t2] = X_t2' X_t of block b for t2 > t, else 0
+    const double* cg;     // [nit][16][16]  column t of block b's Gram matrix (X_t2' X_t for t2 > t, else 0),
+                          //               entry t2 at [t][t2 % NQ][t2 / NQ], NQ = 4 / T (see the chain role)
     const double* ax;     // [L - 1][nit + 1][64][4]  A operands of (X_b' X_{b-l}), l = 1 .. L-1
-    const double* sc2;    // [16 nit][2]   lod, xtx of every step (inactive steps: 0, 0)
+    const double* sc2;    // [16 nit][4]   lod, xtx, g[t][t+1] (Gram entry below the diagonal), 0 of every
+                          //               step (inactive steps: zeros)
     const int* jidx;      // [16 nit]      covariate of every step (inactive: 0)
     const double* scale;  // per-response constants, as SweepParams
     const double* hinv;
@@ -183,7 +185,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     __shared__ __align__(16) double dl[DR * TB];         // deltas                      [blk & 7][t][k]
     __shared__ __align__(16) double mg[2 * 2 * TB];      // mu, gamma of a chain block  [par][2][t][k]
     __shared__ __align__(16) double gram[2 * 256];       // Gram columns of a chain block [par][t][t2]
-    __shared__ __align__(16) double scl[2 * 32];         // lod, xtx of its steps       [par][t][2]
+    __shared__ __align__(16) double scl[2 * 64];         // lod, xtx, g[t][t+1], - of its steps [par][t][4]
     // CS > 1: A operands of the lag-1 cross-block correction of a block, staged by the helper [par][lane][4]
     __shared__ __align__(16) double axl[(CS > 1) ? 2 * 256 : 2];
     // CS > 1: corrections of the lags 2 .. L-1 (matrix waves 1 .. L-2), D layout, and their flags
@@ -197,6 +199,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     // barriers of it + 1 and it + 2: all waves see it at the same iteration.
     __shared__ int dead;
     __shared__ __align__(16) double etab[64];   // 2^(j/64): the chain wave's exponential (fastmath.h)
+    // what the chain wave's lane groups 1 .. NQ-1 "store" (same values as group 0, never read): a
+    // region as long as the offsets of a step's three result stores reach
+    __shared__ double junk[2 * TB + 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -220,7 +225,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
     for (int e = tid; e < 4 * TB; e += 512) gxbo[e] = 0.0;
     for (int e = tid; e < 4 * TB; e += 512) mg[e] = 0.0;
     for (int e = tid; e < 512; e += 512) gram[e] = 0.0;
-    if (tid < 64) scl[tid] = 0.0;
+    if (tid < 128) scl[tid] = 0.0;
     if (tid < 128) jl[tid] = 0;
     if (tid == 0) { prog = 0; gfin_ready = -1; dead = 0; }
     if (tid < 4) cxf[tid] = -1;
@@ -510,8 +515,17 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         }
     } else if (w == CHAIN_W) {
         // =========================== chain role ===========================================
-        const int kc = k0 + lane;
-        const bool cvalid = (lane < TW) && (kc < kend);
+        // The wave's 64 lanes are NQ = 64 / (16 T) groups of 16 T lanes.  Every group runs the same
+        // chain for the same 16 T responses (lane & (TW - 1)) -- same instructions, so it costs
+        // nothing -- and keeps ITS share of the in-block corrections: group q owns corr[t2] for
+        // t2 = NQ i + q.  One FMA then applies a delta to NQ later steps at once (38 per block
+        // instead of 120 at T = 1: every fp64 instruction of this wave costs ~5.7 cycles, on the
+        // dependent path or off it), and the one correction a step needs from another group comes
+        // through a ds_bpermute, which is not a vector-ALU instruction.
+        constexpr int NQ = 64 / TW, NI = kBlk / NQ;
+        const int rr = lane & (TW - 1), qq = lane / TW;
+        const int kc = k0 + rr;
+        const bool cvalid = kc < kend;
         double c_scale = 0.0, c_hinv = 0.0, c_cst = 0.0;
         if (cvalid) {
             c_scale = P.scale[kc];
@@ -528,13 +542,15 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             }
             M1STAMP(0);
             const int b = it - L + 1;  // block whose chain runs now
-            if (b >= 0 && b < P.nblk && lane < TW) {
-                const double* gx_l = gx + (b & 1) * 2 * TB + lane;
-                const double* bo_l = bol + (b & 1) * 2 * TB + lane;
-                double* dl_w = dl + (b & (DR - 1)) * TB + lane;
-                double* mg_w = mg + (b & 1) * 2 * TB + lane;
-                const double* sc_b = scl + (b & 1) * 32;      // wave-uniform addresses: broadcast reads
-                const double* cg_b = gram + (b & 1) * 256;
+            if (b >= 0 && b < P.nblk) {
+                const double* gx_l = gx + (b & 1) * 2 * TB + rr;
+                const double* bo_l = bol + (b & 1) * 2 * TB + rr;
+                // results: group 0 writes them, the other groups write the same values to a spare
+                // slot of their own (no lane mask inside the step)
+                double* dl_w = (qq == 0) ? dl + (b & (DR - 1)) * TB + rr : junk + lane;
+                double* mg_w = (qq == 0) ? mg + (b & 1) * 2 * TB + rr : junk + lane;
+                const double* sc_b = scl + (b & 1) * 64;      // wave-uniform addresses: broadcast reads
+                const double* cg_l = gram + (b & 1) * 256 + qq * NI;   // this group's entries of a column
 
                 // The dependent path of a step is cut to: dot -> dot^2 -> a -> exp -> 1 + e -> divide
                 // -> dot of the NEXT step (one FMA).  With
@@ -548,19 +564,21 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 // the next dot).  coreLoop.cpp:42-48, re-associated (rounding-level differences).
                 const double cA = cfac * c_scale * c_scale * c_hinv;
                 const double cC = cfac * c_cst;
-                double corr[kBlk];  // corr[t2] = sum over the steps s whose delta is applied of g[s][t2] d_s
+                // corr[i] = sum over the steps s whose delta is applied of g[s][t2] d_s, t2 = NQ i + qq
+                double corr[NI];
 #pragma unroll
-                for (int t = 0; t < kBlk; ++t) corr[t] = 0.0;
+                for (int i = 0; i < NI; ++i) corr[i] = 0.0;
                 double bo_c = bo_l[0];
                 double2 sc_c = *reinterpret_cast<const double2*>(sc_b);
+                double sd_c = sc_b[2];                 // g[t][t+1] of the current step
                 double dot = fma(sc_c.y, bo_c, gx_l[0]);
                 // step t - 1, finished but not yet written / applied
                 double m_p = 0.0, gam_p = 0.0, bo_p = 0.0;
-                // Gram columns of the steps t (even / odd): column t is requested in step t, gives
-                // g[t][t+1] at its end and the corrections of the later steps during step t + 1
-                double gc0[kBlk], gc1[kBlk];
+                // this group's entries of the Gram columns of the steps t (even / odd): column t is
+                // requested in step t and applied, with delta_t, during step t + 1
+                double gc0[NI], gc1[NI];
 #pragma unroll
-                for (int t = 0; t < kBlk; ++t) gc0[t] = gc1[t] = 0.0;
+                for (int i = 0; i < NI; ++i) gc0[i] = gc1[i] = 0.0;
                 // The compiler's scheduler puts the whole dependent chain first and everything
                 // else behind it (on the path); so the step is written as the chain's instructions
                 // one by one, each fenced together with the off-path work that fills its latency.
@@ -568,32 +586,28 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 LOCUS_FENCE();
                 sfor<kBlk>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
-                    double (&gc)[kBlk] = (t & 1) ? gc1 : gc0;    // column t
-                    double (&gp)[kBlk] = (t & 1) ? gc0 : gc1;    // column t - 1
+                    double (&gc)[NI] = (t & 1) ? gc1 : gc0;    // column t
+                    double (&gp)[NI] = (t & 1) ? gc0 : gc1;    // column t - 1
+                    // column s updates corr[t2] for t2 >= s + 2 (t2 = s + 1 goes through `pre`):
+                    // entries i >= (s + 2) / NQ of a lane (what lies below that in entry i is dead
+                    // or zero: harmless)
+                    constexpr int ILO = (t + 2) / NQ;          // first entry of column t that is used
+                    constexpr int IPL = (t + 1) / NQ;          // ... of column t - 1
                     double delta = 0.0, m = 0.0, bo_n = 0.0, gx_n = 0.0, base = 0.0, pre = 0.0, gm = 0.0;
+                    double sd_n = 0.0, cnx = 0.0;
                     double2 sc_n = make_double2(0.0, 0.0);
-                    // corrections of the steps t + 2 + i by the delta of step t - 1
-                    auto corr_upd = [&](auto ic) {
-                        constexpr int t2 = t + 2 + decltype(ic)::value;
-                        if constexpr (t > 0 && t2 < kBlk) corr[t2] = fma(gp[t2], delta, corr[t2]);
-                    };
                     using std::integral_constant;
                     const double lod = sc_c.x;
                     const double cB = fma(cfac, lod, cC);
 
                     const double dd = dot * dot;
                     if constexpr (t + 1 < kBlk) {   // requests for step t + 1
-                        // column t of the block's Gram matrix, entries t + 1 .. 15, as 16-byte pairs
-                        // (the pair that holds entry t + 1 may start at the zero diagonal entry)
-                        sfor<8 - ((t + 1) >> 1)>([&](auto c2) {
-                            constexpr int t2 = 2 * (((t + 1) >> 1) + decltype(c2)::value);
-                            const double2 g2 = *reinterpret_cast<const double2*>(cg_b + t * 16 + t2);
-                            gc[t2] = g2.x;
-                            gc[t2 + 1] = g2.y;
-                        });
+#pragma unroll
+                        for (int i = ILO; i < NI; ++i) gc[i] = cg_l[t * 16 + i];
                         bo_n = bo_l[(t + 1) * TW];
-                        sc_n = *reinterpret_cast<const double2*>(sc_b + 2 * (t + 1));
                         gx_n = gx_l[(t + 1) * TW];
+                        sc_n = *reinterpret_cast<const double2*>(sc_b + 4 * (t + 1));
+                        sd_n = sc_b[4 * (t + 1) + 2];
                     }
                     LOCUS_FENCE();
                     const double a = fma(-cA, dd, cB);                         // coreLoop.cpp:42-46
@@ -604,11 +618,23 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     // clamp is v_max / v_min, which drop a NaN: `one`, the numerator, carries it
                     // instead (a NaN log-odds must come out as a NaN gam, src/utils.cpp:3-12).
                     double x = __builtin_fmax(a, -708.0);
-                    if constexpr (t > 0 && t + 1 < kBlk) corr[t + 1] = fma(gp[t + 1], delta, corr[t + 1]);
+                    // delta of step t - 1 into the corrections of the steps >= t + 1, NQ of them per FMA
+                    if constexpr (t > 0) {
+#pragma unroll
+                        for (int i = IPL; i < NI; ++i) corr[i] = fma(gp[i], delta, corr[i]);
+                    }
                     m = c_scale * dot;
                     LOCUS_FENCE();
                     x = __builtin_fmin(x, 705.0);
                     const double one = (a == a) ? 1.0 : a;
+                    // corr[t + 1], complete now, from the group that owns it to every lane
+                    if constexpr (t > 0 && t + 1 < kBlk) {
+                        constexpr int QS = (t + 1) % NQ, IS = (t + 1) / NQ;
+                        const int src = (QS * TW + rr) * 4;
+                        const int lo_ = __builtin_amdgcn_ds_bpermute(src, __double2loint(corr[IS]));
+                        const int hi_ = __builtin_amdgcn_ds_bpermute(src, __double2hiint(corr[IS]));
+                        cnx = __hiloint2double(hi_, lo_);
+                    }
                     LOCUS_FENCE();
                     // N = round(64 x / ln 2) sits in the low word of x (64 / ln 2) + 1.5 2^52
                     const double kf0 = fma(x, 92.33248261689366, 6755399441055744.0);
@@ -622,43 +648,29 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     const double nf = kf0 - 6755399441055744.0;
                     const int nn = __double2loint(kf0);
                     const double tj = etab[nn & 63];                            // 2^(j/64)
-                    corr_upd(integral_constant<int, 0>{});
-                    corr_upd(integral_constant<int, 1>{});
                     LOCUS_FENCE();
                     double r = fma(nf, -6.93147180369123816490e-01 / 64, x);
                     const int kx = nn >> 6;
-                    corr_upd(integral_constant<int, 2>{});
-                    corr_upd(integral_constant<int, 3>{});
                     LOCUS_FENCE();
                     r = fma(nf, -1.90821492927058770002e-10 / 64, r);
-                    corr_upd(integral_constant<int, 4>{});
-                    corr_upd(integral_constant<int, 5>{});
                     LOCUS_FENCE();
                     const double r2 = r * r;
                     const double pa = fma(r, 1.66666666666666666667e-01, 0.5);
                     const double pb = fma(r, 8.33333333333333333333e-03, 4.16666666666666666667e-02);
-                    corr_upd(integral_constant<int, 6>{});
                     LOCUS_FENCE();
                     const double pc = fma(pb, r2, pa);
-                    corr_upd(integral_constant<int, 7>{});
-                    corr_upd(integral_constant<int, 8>{});
                     LOCUS_FENCE();
                     const double pd_ = fma(pc, r2, r);                          // exp(r) - 1
-                    corr_upd(integral_constant<int, 9>{});
-                    corr_upd(integral_constant<int, 10>{});
                     LOCUS_FENCE();
                     const double pe = fma(tj, pd_, tj);
-                    corr_upd(integral_constant<int, 11>{});
                     if constexpr (t + 1 < kBlk) base = fma(sc_n.y, bo_n, gx_n);
                     LOCUS_FENCE();
                     const double e = __builtin_ldexp(pe, kx);
-                    corr_upd(integral_constant<int, 12>{});
-                    corr_upd(integral_constant<int, 13>{});
                     LOCUS_FENCE();
                     const double den = 1.0 + e;
                     if constexpr (t + 1 < kBlk) {
-                        pre = fma(gc[t + 1], bo_c, corr[t + 1]);
-                        gm = gc[t + 1] * m;
+                        pre = fma(sd_c, bo_c, cnx);
+                        gm = sd_c * m;
                     }
                     LOCUS_FENCE();
                     // the hardware reciprocal (2^-24.4), ONE Newton step and the quotient's own
@@ -682,6 +694,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     bo_p = bo_c;
                     bo_c = bo_n;
                     sc_c = sc_n;
+                    sd_c = sd_n;
                     LOCUS_FENCE();
                 });
 #undef LOCUS_FENCE
@@ -963,8 +976,8 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     reinterpret_cast<const double2*>(P.cg + (size_t)256 * bn_blk) + 2 * lane;
                 gr_v[0] = gsrc[0];
                 gr_v[1] = gsrc[1];
-                if (lane < 16)
-                    sc_v = reinterpret_cast<const double2*>(P.sc2 + (size_t)32 * bn_blk)[lane];
+                if (lane < 32)
+                    sc_v = reinterpret_cast<const double2*>(P.sc2 + (size_t)64 * bn_blk)[lane];
                 {
                     const int* jp = jl + (bn_blk & 7) * 16 + q;
 #pragma unroll
@@ -1011,7 +1024,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                 double2* gp = reinterpret_cast<double2*>(gram + (bn_blk & 1) * 256) + 2 * lane;
                 gp[0] = gr_v[0];
                 gp[1] = gr_v[1];
-                if (lane < 16) reinterpret_cast<double2*>(scl + (bn_blk & 1) * 32)[lane] = sc_v;
+                if (lane < 32) reinterpret_cast<double2*>(scl + (bn_blk & 1) * 64)[lane] = sc_v;
             }
             if (lane < 16) jl[(jn_blk & 7) * 16 + lane] = jv;
             if constexpr (CS > 1) {
