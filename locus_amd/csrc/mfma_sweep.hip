@@ -152,9 +152,9 @@ pack_blocks1_kernel(const double* __restrict__ Xp, const StepRec* __restrict__ s
         gsum[l] = a;
     }
     // Column t = gs of the block's Gram matrix, strictly below the diagonal, in the order the chain
-    // wave's lanes read it (mfma_sweep1_kernel.h): its 64 lanes are NQ = 64 / (16 T) groups that run
-    // the same 16 T responses, group q keeps the corrections of the steps t' = NQ i + q, so entry t'
-    // sits at [t][q = t' % NQ][i = t' / NQ].  The entry right below the diagonal, which every lane
+    // wave's lanes read it (mfma_sweep1_kernel.h): its 64 lanes are NQ groups (mfma1_lane_groups: 1,
+    // or 64 / (16 T)) that run the same 16 T responses, group q keeps the corrections of the steps
+    // t' = NQ i + q, so entry t' sits at [t][q = t' % NQ][i = t' / NQ].  The entry right below the diagonal, which every lane
     // needs, also goes to the step's scalars {lod, xtx, g[t][t+1], 0}.
     cg[(size_t)b * 256 + gs * 16 + (gt % NQ) * (16 / NQ) + gt / NQ] = (gt > gs) ? gsum[0] : 0.0;
     if (gt == ((gs + 1) & 15)) sc2[(size_t)(16 * b + gs) * 4 + 2] = (gs < 15) ? gsum[0] : 0.0;
@@ -512,14 +512,16 @@ static int pack_and_launch1(const SweepParams& prm, int T, int CS, Tiling1 til, 
         const size_t lds = sizeof(double) * (size_t)L * 16 * 130 + sizeof(int) * 16 * L;
         if (L == 3) {
             hipLaunchKernelGGL(pack_blocks1_kernel<3>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
-                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD, 4 / T);
+                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD,
+                               mfma1_lane_groups(KT, CS, T, ODD));
         } else {
             // 83 KB of dynamic LDS: above the 64 KB default limit.  The attribute belongs to the
             // (function, device) pair, so it is set before every launch (cheap; as in gemm.hip).
             LOCUS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pack_blocks1_kernel<5>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(pack_blocks1_kernel<5>, dim3((unsigned)nit), dim3(256), lds, st, prm.Xp,
-                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD, 4 / T);
+                               prm.steps, XS, cgp, axp, sc2, jidx, prm.ld, KT, nblk, NW, prm.nsteps, ODD,
+                               mfma1_lane_groups(KT, CS, T, ODD));
         }
         LOCUS_HIP_CHECK(hipGetLastError());
     }
@@ -611,8 +613,9 @@ static int choose_cs(int n, int tiles)
 //   one tile of 16 responses on 1, 2, 3 CUs: bound by the matrix waves (their operand fetch
 //        through the CU's L1 and their MFMAs): 5.15 at kt = 10.5 alone (0.49 kt), 3.0 at kt = 5.5
 //        in a cluster of two (0.55 kt);
-//        or by the chain wave: 2.5 - 2.8 alone (2.4 + 0.08 kt), 2.6 in a cluster of two, 2.75 of
-//        three (with the cluster hand-over)
+//        or by the chain wave: 2.2 / 2.8 at kt = 2.5 / 4.5 alone (1.48 + 0.29 kt: matrix wave 0
+//        follows it), 2.3 in a cluster of two, 2.44 / 2.66 at kt = 1.5 / 3.5 in one of three
+//        (2.3 + 0.1 kt, with the cluster hand-over)
 //   two tiles (32 responses) on 2, 3 CUs: matrix-bound, 5.68 at kt = 5.5 on two (1.04 kt), 3.78 at
 //        kt = 3.5 on three (1.08 kt); or by the chain wave and the helper, which serve two tiles:
 //        3.33 / 3.82 at kt = 1.5 / 2.5 on three, 3.55 at 2.5 on two (3.0 + 0.25 kt)
@@ -654,7 +657,7 @@ static std::vector<LaunchType> launch_types(int n)
             if (til.KT == 0 || (CS > 1 && c < 8 * CS)) continue;
             const int clusters = (CS == 1) ? c : (c / (8 * CS)) * 8;
             const double chain = (T == 2) ? 3.0 + 0.25 * kt
-                                          : (CS == 1 ? 2.4 + 0.08 * kt : (CS == 2 ? 2.6 : 2.75));
+                                          : (CS == 1 ? 1.48 + 0.29 * kt : (CS == 2 ? 2.3 : 2.3 + 0.1 * kt));
             const double work = (T == 2) ? (CS == 2 ? 1.04 : 1.08) * kt : (CS == 1 ? 0.49 : 0.55) * kt;
             v.push_back({T, CS, til.KT, til.ODD, 16 * T * clusters, std::max(work, chain) + pack});
         }

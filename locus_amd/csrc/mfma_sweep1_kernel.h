@@ -53,7 +53,7 @@ struct Mfma1Params {
                           // nothing from then on and leave R as it was before the sweep
     const double* XS;     // [CS * 6][nit][8 KT][64] operand streams (pack_blocks_kernel), nit = nblk + L
     const double* cg;     // [nit][16][16]  column t of block b's Gram matrix (X_t2' X_t for t2 > t, else 0),
-                          //               entry t2 at [t][t2 % NQ][t2 / NQ], NQ = 4 / T (see the chain role)
+                          //               entry t2 at [t][t2 % NQ][t2 / NQ], NQ = mfma1_lane_groups()
     const double* ax;     // [L - 1][nit + 1][64][4]  A operands of (X_b' X_{b-l}), l = 1 .. L-1
     const double* sc2;    // [16 nit][4]   lod, xtx, g[t][t+1] (Gram entry below the diagonal), 0 of every
                           //               step (inactive steps: zeros)
@@ -158,6 +158,19 @@ __host__ __device__ constexpr int mfma1_member_tiles(int KT, int ODD) { return 3
 __host__ __device__ constexpr int mfma1_wave_tile0(int m, int KT, int ODD)
 {
     return m < 3 ? m * KT : 3 * KT + (m - 3) * (KT - ODD);
+}
+
+// Lane groups of the chain wave (see the chain role): 64 / (16 T) groups that run the same chain and
+// share the in-block corrections where the chain wave is what a block waits for, one group where
+// the matrix waves are (there the groups' wider LDS traffic only delays the matrix waves' operand
+// reads: two-member clusters at n = 1000, d = 2000 took 10.4 ms with groups, 10.1 without).
+// Thresholds: where the cost model of the launch plan (mfma_sweep.hip) puts the crossover, in
+// half-tiles per matrix wave (2 kt = 2 KT - ODD).
+__host__ __device__ constexpr int mfma1_lane_groups(int KT, int CS, int T, int ODD)
+{
+    const int kt2 = 2 * KT - ODD;
+    if (T == 2) return kt2 <= 7 ? 2 : 1;
+    return kt2 <= (CS == 1 ? 14 : (CS == 2 ? 8 : 10)) ? 4 : 1;
 }
 
 template <int KT, int CS, int T = 1, int ODD = 0>
@@ -522,8 +535,9 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
         // instead of 120 at T = 1: every fp64 instruction of this wave costs ~5.7 cycles, on the
         // dependent path or off it), and the one correction a step needs from another group comes
         // through a ds_bpermute, which is not a vector-ALU instruction.
-        constexpr int NQ = 64 / TW, NI = kBlk / NQ;
-        const int rr = lane & (TW - 1), qq = lane / TW;
+        // (NQ = 1 where the matrix waves bind, mfma1_lane_groups(): the plain form, lanes >= 16 T idle)
+        constexpr int NQ = mfma1_lane_groups(KT, CS, T, ODD), NI = kBlk / NQ;
+        const int rr = lane & (TW - 1), qq = (NQ == 1) ? 0 : lane / TW;
         const int kc = k0 + rr;
         const bool cvalid = kc < kend;
         double c_scale = 0.0, c_hinv = 0.0, c_cst = 0.0;
@@ -542,7 +556,7 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
             }
             M1STAMP(0);
             const int b = it - L + 1;  // block whose chain runs now
-            if (b >= 0 && b < P.nblk) {
+            if (b >= 0 && b < P.nblk && (NQ > 1 || lane < TW)) {
                 const double* gx_l = gx + (b & 1) * 2 * TB + rr;
                 const double* bo_l = bol + (b & 1) * 2 * TB + rr;
                 // results: group 0 writes them, the other groups write the same values to a spare
@@ -630,10 +644,14 @@ __global__ void __launch_bounds__(512) mfma_sweep1_kernel(const Mfma1Params P)
                     // corr[t + 1], complete now, from the group that owns it to every lane
                     if constexpr (t > 0 && t + 1 < kBlk) {
                         constexpr int QS = (t + 1) % NQ, IS = (t + 1) / NQ;
-                        const int src = (QS * TW + rr) * 4;
-                        const int lo_ = __builtin_amdgcn_ds_bpermute(src, __double2loint(corr[IS]));
-                        const int hi_ = __builtin_amdgcn_ds_bpermute(src, __double2hiint(corr[IS]));
-                        cnx = __hiloint2double(hi_, lo_);
+                        if constexpr (NQ == 1) {
+                            cnx = corr[IS];
+                        } else {
+                            const int src = (QS * TW + rr) * 4;
+                            const int lo_ = __builtin_amdgcn_ds_bpermute(src, __double2loint(corr[IS]));
+                            const int hi_ = __builtin_amdgcn_ds_bpermute(src, __double2hiint(corr[IS]));
+                            cnx = __hiloint2double(hi_, lo_);
+                        }
                     }
                     LOCUS_FENCE();
                     // N = round(64 x / ln 2) sits in the low word of x (64 / ln 2) + 1.5 2^52
