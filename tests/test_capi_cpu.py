@@ -193,6 +193,32 @@ def test_launch_plan_covers_every_response_once(n, cus, monkeypatch):
         assert sorted(geom_of_region) == list(range(len(geom_of_region)))
 
 
+def test_launch_plan_prices_the_chain(monkeypatch):
+    """Few rows per response: the 32-response kernel would be bound by its chain wave (4.85 us per
+    block at n = 200), one tile per CU is not -- the plan must know (round 3: n = 200, d = 1000 ran
+    in 6.3 ms on the 32-response kernel, 2.9 ms with one tile per CU).  At n = 1000 the 32-response
+    kernel is matrix-bound and stays the choice for d >= 5121."""
+    import ctypes as C
+    from locus_amd import _lib
+    for k in ("LOCUS_HIP_SWEEP_CFG", "LOCUS_HIP_MFMA_PLAN", "LOCUS_HIP_MFMA_CS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LOCUS_HIP_MFMA_CUS", "256")
+    lib = _lib.lib()
+    rows = (C.c_int32 * (8 * 64))()
+
+    def plan(n, d):
+        k = lib.locus_hip_sweep_plan(n, d, rows, 64)
+        return [tuple(rows[8 * r: 8 * r + 8]) for r in range(k)]
+
+    assert all(r[1] >= 1 for r in plan(200, 1000))          # clusters (CS >= 1), not CS = 0
+    assert all(r[1] >= 1 for r in plan(400, 1000))
+    big = plan(1000, 10000)
+    assert big[0][:2] == (2, 0) and big[0][5] == 8192       # the 32-response kernel on 256 CUs
+    assert big[-1][1] >= 1 and big[-1][5] == 10000          # the remainder in clusters
+    assert [r[:2] for r in plan(1000, 5000)] == [(2, 3), (2, 3)]   # two launches of 80 three-CU clusters
+    assert [r[:2] for r in plan(1000, 1250)] == [(1, 3)]
+
+
 def test_rcpp_glue_calls_match_the_header():
     """integration/rcpp/*.cpp cannot be compiled here (no R / Rcpp in the image): at least every
     locus_hip_* call in it must name a declared entry point and pass as many arguments as the
