@@ -532,6 +532,20 @@ class IdentityEngine:
             return a
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
 
+    def _up_many(self, *arrays):
+        """Several host arrays in ONE host-to-device copy: returns device views of their shapes (the
+        per-iteration constants of the drivers whose tail runs on the host)."""
+        host = [i for i, a in enumerate(arrays) if not self.torch.is_tensor(a)]   # tensors pass through
+        flat = [np.ascontiguousarray(arrays[i], dtype=np.float64).reshape(-1) for i in host]
+        out = list(arrays)
+        if host:
+            buf = self.torch.from_numpy(np.concatenate(flat)).to(self.device)
+            o = 0
+            for i, f in zip(host, flat):
+                out[i] = buf[o:o + f.size].reshape(np.shape(arrays[i]))
+                o += f.size
+        return out
+
     def initialise(self):
         """beta = gam * mu, mat_x_m1 = X beta (fp64 MFMA GEMM), residual, statistics
         (R/locus_core.R:36-42)."""

@@ -155,13 +155,13 @@ class ZEngine(IdentityEngine):
         n, d = self.n, self.d_loc
         prm = self.host.begin_iteration(c)
         ind = shuffled_ind if t.is_tensor(shuffled_ind) else self._up(shuffled_ind)
-        coef = self._up(prm["alpha_coef"])
+        # the iteration's constants in one upload (seven small copies before)
+        coef, lo, l1, scale, hinv, cst, s2k = self._up_many(
+            prm["alpha_coef"], prm["lo"], prm["l1"], prm["scale"], prm["hinv"], prm["cst"], prm["s2k"])
         for i in (range(self.q) if alpha_order is None else alpha_order):            # :96-103
             dv.alpha_step(self.Y, None, self.M, self.Zmu, self.Zt[i], coef[i], self.alpha[i], n, d)
         dv.residual(self.Y, self.M, self.Zmu, out=self.R)
-        self.sweeper.identity(ind, self._up(prm["lo"]), self._up(prm["l1"]),
-                              self._up(prm["scale"]), self._up(prm["hinv"]), self._up(prm["cst"]),
-                              self._up(prm["s2k"]), c, self.R, self.state, self.stats)
+        self.sweeper.identity(ind, lo, l1, scale, hinv, cst, s2k, c, self.R, self.state, self.stats)
         dv.residual(self.Y, self.R, self.Zmu, out=self.M)                            # M = Y - R - Zmu
         rs_gam, ent = dv.gamma_rows(self.state[0], self.p, d,
                                     eps=self.host.ent_eps if with_elbo else None)
