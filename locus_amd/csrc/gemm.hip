@@ -24,7 +24,9 @@
 // tile's first row instead of being masked (they only feed output rows that are never stored),
 // and squaring is compiled in only when asked.  Removing ~28 VALU instructions per 8 MFMAs took
 // the C3 init product from 46 to 58 TFLOP/s.
-// Shipped: TW = 2 (64 x 64), KS = 2, BK = 16 (41 KB of LDS, three workgroups per CU), BK = 32 when
+// Shipped: 64 x 128 tiles (TWM = 2, TWN = 4, KS = 2, BK = 16; 58 KB of LDS, two workgroups per CU)
+// for products with many output tiles and an unsplit contraction, else
+// TW = 2 (64 x 64), KS = 2, BK = 16 (41 KB of LDS, three workgroups per CU), BK = 32 when
 // there is at most about one output tile per CU.  Measured on MI355X (scripts/perf_gemm.py):
 // 58.3 TFLOP/s (74 % of peak) on the C3 mat_x_m1, 49-50 on the C2 coreBatch products, 43-46 on
 // the C4 X^2 products.  TW = 4 (128 x 128, one workgroup per CU) stays behind LOCUS_HIP_GEMM_TW=4
@@ -62,12 +64,13 @@ __device__ __forceinline__ double ld_elem(const char* base, O off)
 // strides), so the K loop has no vector address arithmetic at all: the bases advance on the scalar
 // unit.  On gfx950 the fp64 MFMA runs on the SIMD's fp64 vector lanes (same 78.6 TFLOP/s peak):
 // every vector instruction a wave issues is time the matrix pipe of that SIMD does not get.
-template <int TW, int KS, int BK, int SQ, bool OFF32>
+template <int TWM, int TWN, int KS, int BK, int SQ, bool OFF32>
 __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 {
-    constexpr int BM = 32 * TW, BN = 32 * TW;
+    constexpr int BM = 32 * TWM, BN = 32 * TWN;   // a wave owns TWM x TWN MFMA tiles of 16 x 16
     constexpr int NT = 256 * KS;        // KS groups of 4 waves split the k-steps of every K-tile
-    constexpr int NQ = BM * BK / NT;    // elements of each operand tile per thread
+    constexpr int NQA = BM * BK / NT;   // elements of the A tile per thread
+    constexpr int NQB = BN * BK / NT;   // ... of the B tile
     constexpr int LDA = BM + LDP, LDB = BN + LDP;
     constexpr int ASZ = 2 * BK * LDA, BSZ = 2 * BK * LDB;
     __shared__ double lds[ASZ + BSZ];  // one array: the KS == 2 epilogue reuses all of it
@@ -106,53 +109,56 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
     const bool b_kfast = (g.sb_k == 1);
     const char* Ab = reinterpret_cast<const char*>(g.A + (long)m0 * g.sa_m + (long)kb * g.sa_k);
     const char* Bb = reinterpret_cast<const char*>(g.B + (long)n0 * g.sb_n + (long)kb * g.sb_k);
-    off_t oa[NQ], ob[NQ];
-    int ak[NQ], bk[NQ];
-    double* al[NQ];  // where the element goes in buffer 0 of its LDS tile
-    double* bl[NQ];
+    off_t oa[NQA], ob[NQB];
+    int ak[NQA], bk[NQB];
+    double* al[NQA];  // where the element goes in buffer 0 of its LDS tile
+    double* bl[NQB];
+    // rows beyond the matrix read the tile's first row: they only feed output rows that are
+    // never stored
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < NQA; ++q) {
         const int e = tid + q * NT;
-        int am, bn;
+        int am;
         if (a_kfast) { ak[q] = e % BK; am = e / BK; } else { am = e % BM; ak[q] = e / BM; }
-        if (b_kfast) { bk[q] = e % BK; bn = e / BK; } else { bn = e % BN; bk[q] = e / BN; }
-        // rows beyond the matrix read the tile's first row: they only feed output rows that are
-        // never stored
         const long ea = (long)(m0 + am < g.m ? am : 0) * g.sa_m + (long)ak[q] * g.sa_k;
-        const long eb = (long)(n0 + bn < g.n ? bn : 0) * g.sb_n + (long)bk[q] * g.sb_k;
         oa[q] = (off_t)(ea * 8);
-        ob[q] = (off_t)(eb * 8);
         al[q] = lds + ak[q] * LDA + am;
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+        const int e = tid + q * NT;
+        int bn;
+        if (b_kfast) { bk[q] = e % BK; bn = e / BK; } else { bn = e % BN; bk[q] = e / BN; }
+        const long eb = (long)(n0 + bn < g.n ? bn : 0) * g.sb_n + (long)bk[q] * g.sb_k;
+        ob[q] = (off_t)(eb * 8);
         bl[q] = lds + ASZ + bk[q] * LDB + bn;
     }
     const long da = (long)BK * g.sa_k * 8, db = (long)BK * g.sb_k * 8;
     // this lane's operands of k-step 0 in buffer 0
-    const double* ar = lds + (4 * ks + (lane >> 4)) * LDA + wm * 16 * TW + (lane & 15);
-    const double* br = lds + ASZ + (4 * ks + (lane >> 4)) * LDB + wn * 16 * TW + (lane & 15);
+    const double* ar = lds + (4 * ks + (lane >> 4)) * LDA + wm * 16 * TWM + (lane & 15);
+    const double* br = lds + ASZ + (4 * ks + (lane >> 4)) * LDB + wn * 16 * TWN + (lane & 15);
 
-    double4_t acc[TW][TW];
+    double4_t acc[TWM][TWN];
 #pragma unroll
-    for (int i = 0; i < TW; ++i)
+    for (int i = 0; i < TWM; ++i)
 #pragma unroll
-        for (int j = 0; j < TW; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < TWN; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     // A tile travels global memory -> registers (raw values, nothing depends on them until the
     // next iteration, so the loads stay in flight behind a whole K-tile of MFMAs) -> LDS (squared
     // there when asked).  Interior K-tiles load without any mask; only the last one checks k.
-    double ra[NQ], rb[NQ];
+    double ra[NQA], rb[NQB];
     auto load_tile = [&](int k0) {  // tile starting at k0 -> registers; advances the bases
         if (k0 + BK <= kend) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                ra[q] = ld_elem<OFF32>(Ab, oa[q]);
-                rb[q] = ld_elem<OFF32>(Bb, ob[q]);
-            }
+            for (int q = 0; q < NQA; ++q) ra[q] = ld_elem<OFF32>(Ab, oa[q]);
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) rb[q] = ld_elem<OFF32>(Bb, ob[q]);
         } else {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                ra[q] = (k0 + ak[q] < kend) ? ld_elem<OFF32>(Ab, oa[q]) : 0.0;
-                rb[q] = (k0 + bk[q] < kend) ? ld_elem<OFF32>(Bb, ob[q]) : 0.0;
-            }
+            for (int q = 0; q < NQA; ++q) ra[q] = (k0 + ak[q] < kend) ? ld_elem<OFF32>(Ab, oa[q]) : 0.0;
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) rb[q] = (k0 + bk[q] < kend) ? ld_elem<OFF32>(Bb, ob[q]) : 0.0;
         }
         Ab += da;
         Bb += db;
@@ -164,29 +170,31 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
         constexpr int buf = decltype(bufc)::value;
         if (k0 + BK < kend) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                double va = ra[q], vb = rb[q];
+            for (int q = 0; q < NQA; ++q) {
+                double va = ra[q];
                 if constexpr (SQ == 1) va = va * va;
-                if constexpr (SQ == 2) {
-                    va = g.sqA ? va * va : va;
-                    vb = g.sqB ? vb * vb : vb;
-                }
+                if constexpr (SQ == 2) va = g.sqA ? va * va : va;
                 al[q][(buf ^ 1) * BK * LDA] = va;
+            }
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) {
+                double vb = rb[q];
+                if constexpr (SQ == 2) vb = g.sqB ? vb * vb : vb;
                 bl[q][(buf ^ 1) * BK * LDB] = vb;
             }
         }
         if (k0 + 2 * BK < kend) load_tile(k0 + 2 * BK);
 #pragma unroll
         for (int s = 0; s < BK / (4 * KS); ++s) {
-            double a[TW], b[TW];
+            double a[TWM], b[TWN];
 #pragma unroll
-            for (int i = 0; i < TW; ++i) a[i] = ar[buf * BK * LDA + 4 * KS * s * LDA + i * 16];
+            for (int i = 0; i < TWM; ++i) a[i] = ar[buf * BK * LDA + 4 * KS * s * LDA + i * 16];
 #pragma unroll
-            for (int j = 0; j < TW; ++j) b[j] = br[buf * BK * LDB + 4 * KS * s * LDB + j * 16];
+            for (int j = 0; j < TWN; ++j) b[j] = br[buf * BK * LDB + 4 * KS * s * LDB + j * 16];
 #pragma unroll
-            for (int i = 0; i < TW; ++i)
+            for (int i = 0; i < TWM; ++i)
 #pragma unroll
-                for (int j = 0; j < TW; ++j)
+                for (int j = 0; j < TWN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -194,14 +202,16 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 
     load_tile(kb);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        double va = ra[q], vb = rb[q];
+    for (int q = 0; q < NQA; ++q) {
+        double va = ra[q];
         if constexpr (SQ == 1) va = va * va;
-        if constexpr (SQ == 2) {
-            va = g.sqA ? va * va : va;
-            vb = g.sqB ? vb * vb : vb;
-        }
+        if constexpr (SQ == 2) va = g.sqA ? va * va : va;
         al[q][0] = va;
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+        double vb = rb[q];
+        if constexpr (SQ == 2) vb = g.sqB ? vb * vb : vb;
         bl[q][0] = vb;
     }
     if (kb + BK < kend) load_tile(kb + BK);
@@ -217,29 +227,29 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
         // tiles when the partial tile is larger than the buffers (TW = 4)
         double* xch = lds;
         constexpr int NH = (BM * BN > ASZ + BSZ) ? 2 : 1;
-        constexpr int TH = TW / NH;  // rows of MFMA tiles per pass
-        static_assert(ASZ + BSZ >= BM * BN / NH && TW % NH == 0, "exchange buffer");
-        const int slot = ((wave * TH * TW) * 4) * 64 + lane;
+        constexpr int TH = TWM / NH;  // rows of MFMA tiles per pass
+        static_assert(ASZ + BSZ >= BM * BN / NH && TWM % NH == 0, "exchange buffer");
+        const int slot = ((wave * TH * TWN) * 4) * 64 + lane;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             if (ks == 1) {
 #pragma unroll
                 for (int i = 0; i < TH; ++i)
 #pragma unroll
-                    for (int j = 0; j < TW; ++j)
+                    for (int j = 0; j < TWN; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            xch[slot + ((i * TW + j) * 4 + r) * 64] = acc[h * TH + i][j][r];
+                            xch[slot + ((i * TWN + j) * 4 + r) * 64] = acc[h * TH + i][j][r];
             }
             __syncthreads();
             if (ks == 0) {
 #pragma unroll
                 for (int i = 0; i < TH; ++i)
 #pragma unroll
-                    for (int j = 0; j < TW; ++j)
+                    for (int j = 0; j < TWN; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            acc[h * TH + i][j][r] += xch[slot + ((i * TW + j) * 4 + r) * 64];
+                            acc[h * TH + i][j][r] += xch[slot + ((i * TWN + j) * 4 + r) * 64];
             }
             if (h + 1 < NH) __syncthreads();
         }
@@ -248,13 +258,13 @@ __global__ void __launch_bounds__(256 * KS) gemm_f64_kernel(const GemmDesc g)
 
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int i = 0; i < TW; ++i)
+    for (int i = 0; i < TWM; ++i)
 #pragma unroll
-        for (int j = 0; j < TW; ++j)
+        for (int j = 0; j < TWN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 16 * TW + i * 16 + (lane >> 4) + 4 * r;
-                const int n = n0 + wn * 16 * TW + j * 16 + (lane & 15);
+                const int m = m0 + wm * 16 * TWM + i * 16 + (lane >> 4) + 4 * r;
+                const int n = n0 + wn * 16 * TWN + j * 16 + (lane & 15);
                 if (m < g.m && n < g.n) {
                     double* c = g.C + (long)blockIdx.z * g.cz + (long)m * g.sc_m + (long)n * g.sc_n;
                     double v = g.alpha * acc[i][j][r];
@@ -283,17 +293,17 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const double* p
 
 // Picks the instantiation: squaring code only when an operand is squared; 32-bit lane offsets when
 // every element of a tile lies within 2^31 bytes after the tile's first one.
-template <int TW, int KS, int BK>
+template <int TWM, int TWN, int KS, int BK>
 static int launch_gemm(const GemmDesc& g, dim3 grid, hipStream_t st)
 {
-    constexpr int BM = 32 * TW;
+    constexpr int BM = 32 * TWM, BN = 32 * TWN;
     const long lim = (1L << 28) - 1;  // elements
     const bool off32 = !getenv("LOCUS_HIP_GEMM_OFF64") && g.sa_m >= 0 && g.sa_k >= 0 &&
                        g.sb_n >= 0 && g.sb_k >= 0 &&
                        (BM - 1) * g.sa_m + (BK - 1) * g.sa_k <= lim &&
-                       (BM - 1) * g.sb_n + (BK - 1) * g.sb_k <= lim;
+                       (BN - 1) * g.sb_n + (BK - 1) * g.sb_k <= lim;
     auto go = [&](auto kern) {
-        if (sizeof(double) * 2 * BK * 2 * (BM + LDP) > 64 * 1024)
+        if (sizeof(double) * 2 * BK * (BM + BN + 2 * LDP) > 64 * 1024)
             LOCUS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 0));
         hipLaunchKernelGGL(kern, grid, dim3(256 * KS), 0, st, g);
@@ -301,13 +311,13 @@ static int launch_gemm(const GemmDesc& g, dim3 grid, hipStream_t st)
     };
     const int sq = (g.sqA && !g.sqB) ? 1 : ((g.sqA || g.sqB) ? 2 : 0);
     if (sq == 1)
-        return off32 ? go(gemm_f64_kernel<TW, KS, BK, 1, true>)
-                     : go(gemm_f64_kernel<TW, KS, BK, 1, false>);
+        return off32 ? go(gemm_f64_kernel<TWM, TWN, KS, BK, 1, true>)
+                     : go(gemm_f64_kernel<TWM, TWN, KS, BK, 1, false>);
     if (sq == 2)
-        return off32 ? go(gemm_f64_kernel<TW, KS, BK, 2, true>)
-                     : go(gemm_f64_kernel<TW, KS, BK, 2, false>);
-    return off32 ? go(gemm_f64_kernel<TW, KS, BK, 0, true>)
-                 : go(gemm_f64_kernel<TW, KS, BK, 0, false>);
+        return off32 ? go(gemm_f64_kernel<TWM, TWN, KS, BK, 2, true>)
+                     : go(gemm_f64_kernel<TWM, TWN, KS, BK, 2, false>);
+    return off32 ? go(gemm_f64_kernel<TWM, TWN, KS, BK, 0, true>)
+                 : go(gemm_f64_kernel<TWM, TWN, KS, BK, 0, false>);
 }
 
 int gemm_f64(const GemmDesc& g_in, hipStream_t st)
@@ -346,12 +356,23 @@ int gemm_f64(const GemmDesc& g_in, hipStream_t st)
     const char* tw = getenv("LOCUS_HIP_GEMM_TW");
     const char* ksv = getenv("LOCUS_HIP_GEMM_KS");
     int rc = 0;
-    if (tw && tw[0] == '4') {
+    // 64 x 128 tiles (a wave owns 2 x 4 MFMA tiles: 6 LDS reads per 8 MFMAs instead of 4 per 4, half
+    // the barriers per MFMA) when the contraction is not split, n pads to 128 as well as to 64 and
+    // there are two workgroups' worth of such tiles for every CU: C3 init 58.8 -> 60.1 TFLOP/s,
+    // X'R of coreBatch 49.9 -> 51.8, (X^2)'(2 psi) 42.6 -> 45.0.  LOCUS_HIP_GEMM_TW=w forces it
+    // (no split-K then), =2 keeps 64 x 64.
+    const bool wide = tw ? tw[0] == 'w'
+                         : (nz == 1 && ((g.n + 127) / 128 * 128) * 100L <= ((g.n + 63) / 64 * 64) * 104L &&
+                            (long)((g.m + 63) / 64) * ((g.n + 127) / 128) >= 2L * device_cus());
+    if (wide) {
+        dim3 grid((g.m + 63) / 64, (g.n + 127) / 128, nz);
+        rc = launch_gemm<2, 4, 2, 16>(g, grid, st);
+    } else if (tw && tw[0] == '4') {
         dim3 grid((g.m + 127) / 128, (g.n + 127) / 128);
         if (ksv && ksv[0] == '2')
-            rc = launch_gemm<4, 2, 16>(g, grid, st);
+            rc = launch_gemm<4, 4, 2, 16>(g, grid, st);
         else
-            rc = launch_gemm<4, 1, 16>(g, grid, st);
+            rc = launch_gemm<4, 4, 1, 16>(g, grid, st);
     } else {
         dim3 grid((g.m + 63) / 64, (g.n + 63) / 64, nz);
         const long tiles = (long)grid.x * grid.y * nz;
@@ -363,11 +384,11 @@ int gemm_f64(const GemmDesc& g_in, hipStream_t st)
         // its barriers (82 KB of LDS: one workgroup per CU, which is all there is anyway)
         const bool deep = bkv ? (bkv[0] == '3') : (tiles <= 384);
         if (split && deep)
-            rc = launch_gemm<2, 2, 32>(g, grid, st);
+            rc = launch_gemm<2, 2, 2, 32>(g, grid, st);
         else if (split)
-            rc = launch_gemm<2, 2, 16>(g, grid, st);
+            rc = launch_gemm<2, 2, 2, 16>(g, grid, st);
         else
-            rc = launch_gemm<2, 1, 16>(g, grid, st);
+            rc = launch_gemm<2, 2, 1, 16>(g, grid, st);
     }
     if (rc) return rc;
     LOCUS_HIP_CHECK(hipGetLastError());

@@ -51,6 +51,37 @@ def test_gemm_f64(hip, m, n, k, layout):
     np.testing.assert_allclose(Ct2.cpu().numpy(), (A * A) @ (B * B), rtol=1e-12, atol=1e-12 * k ** 0.5)
 
 
+@pytest.mark.parametrize("layout", ["nn", "tn", "nt", "tt"])
+@pytest.mark.parametrize("forced", [False, True])
+def test_gemm_f64_wide_tiles(hip, layout, forced, monkeypatch):
+    """The 64 x 128 tile: chosen by itself for many output tiles (4000 x 1279: 63 x 10 tiles on 256 CUs;
+    ragged in m, n and k), and forced on a small ragged shape (LOCUS_HIP_GEMM_TW=w)."""
+    import torch
+    from locus_amd import device as dv
+    if forced:
+        monkeypatch.setenv("LOCUS_HIP_GEMM_TW", "w")
+        m, n, k = 70, 133, 37
+    else:
+        monkeypatch.delenv("LOCUS_HIP_GEMM_TW", raising=False)
+        m, n, k = 4000, 1279, 75
+    rng = np.random.default_rng(m + n + k)
+    A = rng.normal(size=(m, k)); B = rng.normal(size=(k, n)); C0 = rng.normal(size=(m, n))
+    dev = torch.device("cuda:0")
+    if layout[0] == "n":
+        At, sa_m, sa_k = torch.from_numpy(A.copy()).to(dev), k, 1
+    else:
+        At, sa_m, sa_k = torch.from_numpy(A.T.copy()).to(dev), 1, m
+    if layout[1] == "n":
+        Bt, sb_k, sb_n = torch.from_numpy(B.copy()).to(dev), n, 1
+    else:
+        Bt, sb_k, sb_n = torch.from_numpy(B.T.copy()).to(dev), 1, k
+    Ct = torch.from_numpy(C0.copy()).to(dev)
+    dv.gemm(m, n, k, At, sa_m, sa_k, Bt, sb_k, sb_n, Ct, n, 1, alpha=0.5, beta=-2.0)
+    np.testing.assert_allclose(Ct.cpu().numpy(), 0.5 * A @ B - 2.0 * C0, rtol=1e-12, atol=1e-12 * k ** 0.5)
+    dv.gemm(m, n, k, At, sa_m, sa_k, Bt, sb_k, sb_n, Ct, n, 1, sqA=True, sqB=True)
+    np.testing.assert_allclose(Ct.cpu().numpy(), (A * A) @ (B * B), rtol=1e-12, atol=1e-12 * k ** 0.5)
+
+
 @pytest.mark.parametrize("m,n,k", [(70, 33, 19), (200, 130, 257)])
 def test_gemm_f64_negative_stride(hip, m, n, k):
     """A negative stride takes the instantiation with 64-bit lane offsets (the default one
