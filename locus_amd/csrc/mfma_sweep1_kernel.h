@@ -13,11 +13,14 @@
 //       next; with one workgroup per tile matrix wave 0 adds them to the reduced G and follows
 //       the chain's progress word for lag 1;
 //   wave 3 (chain role, with the helper on SIMD 3, which runs no MFMA stream): per step ONE LDS
-//       read of gx, ONE of beta_old, the step's scalars and Gram column as LDS broadcasts, the
-//       update (26 dependent instructions, everything else in their latency gaps), three LDS
-//       writes (delta, mu, gamma).  No global memory access, no partial-sum tree, no address
-//       arithmetic.  In a cluster it also finishes gx of its next block right after its 16th
-//       step (lag 1: four MFMAs on the deltas it just wrote);
+//       read for gx and beta_old, the step's scalars as an LDS broadcast, its share of the Gram
+//       column, the update (21 dependent instructions: gam = 1 / (1 + exp(a)) with a table-driven
+//       exponential; everything else in their latency gaps), three LDS writes (delta, mu, gamma).
+//       Where the chain is what a block waits for, the wave's 64 lanes are 4 (T = 2: 2) groups
+//       that run the same chain and share the in-block corrections (mfma1_lane_groups()).  No
+//       global memory access, no partial-sum tree, no address arithmetic.  In a cluster it also
+//       finishes gx of its next block right after its 16th step (lag 1: four MFMAs on the deltas
+//       it just wrote);
 //   wave 7 (helper role): everything else -- sums the matrix waves' partial G tiles, exchanges
 //       them with the other workgroups of the cluster, stages beta_old, scalars, Gram columns
 //       and cross-Gram operands one block ahead, writes gam / mu / beta of the block the chain
