@@ -374,8 +374,13 @@ def test_wide_vector_geometries(oracle, hip, geom, monkeypatch):
     assert_parity(got, ref, what=f"identity wide geom {geom}")
 
 
-@pytest.mark.parametrize("shape,cus", [((300, 200, 70), None), ((300, 70, 150), "2"), ((130, 40, 5), None)])
-def test_operands_packed_ahead(hip, shape, cus, monkeypatch):
+@pytest.mark.parametrize("shape,cus,only", [((300, 200, 70), None, None), ((300, 70, 150), "2", None),
+                                             ((130, 40, 5), None, None),
+                                             # several launches of ONE geometry share a packed region:
+                                             # one tile per CU on 8 CUs (128 + 22), and clusters of
+                                             # two on 24 CUs (128 + 128 + 44) -- what 2 GPUs do at C3
+                                             ((300, 60, 150), "8", None), ((300, 60, 300), "24", "1,2")])
+def test_operands_packed_ahead(hip, shape, cus, only, monkeypatch):
     """locus_hip_sweep_prepack_dev + locus_hip_sweep_dev(prepacked = 1), as Sweeper.prepack queues
     them on a side stream while another sweep runs: three sweeps in a row with the next one's
     operands packed ahead are bit-identical to three plain sweeps, also when the plan has several
@@ -386,6 +391,8 @@ def test_operands_packed_ahead(hip, shape, cus, monkeypatch):
     monkeypatch.delenv("LOCUS_HIP_SWEEP_CFG", raising=False)
     if cus:
         monkeypatch.setenv("LOCUS_HIP_MFMA_CUS", cus)
+    if only:
+        monkeypatch.setenv("LOCUS_HIP_MFMA_PLAN", only)
     n, p, d = shape
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(12)
