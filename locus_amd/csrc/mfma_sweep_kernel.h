@@ -370,6 +370,7 @@ mfma_sweep_kernel(const MfmaSweepParams P)
                         for (int g = 0; g < 4; ++g) pb[tau * 256 + g * 64] = xc[tau][g];
                 }
             }
+            MSTAMP(2);   // (diagnostic builds: staging stores + cross correction, "upd0+B2" column)
         }
 
 #ifdef LOCUS_STAMPS

@@ -114,7 +114,9 @@ def main():
             a = np.array(buf, dtype=np.float64).reshape(nwg, 8) / ((nsteps + 15) // 16 + 2)
             names = ["w0:B1-wait", "w0:bop+xcorr", "w0:upd0+B2", "w0:update", "w0:dot", "-",
                      "chain:run", "chain:wait"]
-            names = ["B1-wait", "bop+xcorr", "upd0+B2", "update", "dot"]
+            # "end": partial-G and staging stores after the stream; on wave 3 also the cross-block
+            # correction that follows the chain wave
+            names = ["B1-wait", "bop", "end", "update", "dot"]
             for wv in range(MWV):
                 aw = a[wv::MWV]
                 if len(aw):
