@@ -93,8 +93,8 @@ struct LaShared {
 // ---- vector waves 0..5: rows of R, W2, X o W2 -------------------------------------------------
 template <int NPL, int CR>
 __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaShared<CR>& L,
-                                               const int wave, const int lane, const int k0,
-                                               const int nsteps_pad)
+                                               const int wave, const int rowbase, const int lane,
+                                               const int k0, const int nsteps_pad)
 {
     constexpr int D = la_depth<NPL, CR>();  // X ring depth (steps ahead)
     constexpr int NK = 2 * CR;
@@ -104,8 +104,8 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
     // 16-byte loads (half the load instructions; the dot products do not care which lane holds
     // which row).  An odd NPL keeps one 8-byte load for its last register.
     auto row_of = [&](int i) {
-        return (NPL % 2 == 1 && i == NPL - 1) ? wave * NPL * 64 + (NPL - 1) * 64 + lane
-                                              : wave * NPL * 64 + (i >> 1) * 128 + 2 * lane + (i & 1);
+        return (NPL % 2 == 1 && i == NPL - 1) ? rowbase + (NPL - 1) * 64 + lane
+                                              : rowbase + (i >> 1) * 128 + 2 * lane + (i & 1);
     };
     double r[CR][NPL], w[CR][NPL], xw[CR][NPL];
 #pragma unroll
@@ -209,32 +209,37 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
             constexpr int u = uu % D;
             const int s = s0 + uu;
             constexpr int un = (u + 1) % D;  // slot of X_{s+1}
-            // (a) R += (X_{s-1} o W2) delta_{s-1};  (b) xw = X_s o W2
+            // The delta of the last step arrives through LDS right after the barrier: what does
+            // not depend on it goes first and covers the read's latency.
             double dlt[CR];
 #pragma unroll
             for (int cc = 0; cc < CR; ++cc) dlt[cc] = L.dl[((s + 1) & 1) * CR + cc];
+            // (b) xn = X_s o W2;  c = X_{s+1}' xn
+            double pv[CR], cv[CR], xn[CR][NPL];
 #pragma unroll
             for (int cc = 0; cc < CR; ++cc) {
+                double ca = 0.0;
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) {
+                    xn[cc][i] = xr[u][i] * w[cc][i];
+                    ca = fma(xr[un][i], xn[cc][i], ca);
+                }
+                cv[cc] = ca;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (a) R += (X_{s-1} o W2) delta_{s-1};  p = X_{s+1}' R
+#pragma unroll
+            for (int cc = 0; cc < CR; ++cc) {
+                double pa = 0.0;
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
                     r[cc][i] = fma(xw[cc][i], dlt[cc], r[cc][i]);
-                    xw[cc][i] = xr[u][i] * w[cc][i];
-                }
-            }
-            LA_MARK(0);
-            // (c) partial sums of step s + 1: p = X_{s+1}' R, c = X_{s+1}' xw
-            double pv[CR], cv[CR];
-#pragma unroll
-            for (int cc = 0; cc < CR; ++cc) {
-                double pa = 0.0, ca = 0.0;
-#pragma unroll
-                for (int i = 0; i < NPL; ++i) {
                     pa = fma(xr[un][i], r[cc][i], pa);
-                    ca = fma(xr[un][i], xw[cc][i], ca);
+                    xw[cc][i] = xn[cc][i];
                 }
                 pv[cc] = pa;
-                cv[cc] = ca;
             }
+            LA_MARK(0);
             reduce_write(pv, cv, (s + 1) & 1);
             LA_MARK(1);
             // slot u is free: column of step s + D, index of step s + 2 D
@@ -248,7 +253,12 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
         const int o = blockIdx.x * 24;
         g_sweep_stamps[o + 0] = t_busy;
         g_sweep_stamps[o + 1] = t_wait;
-        for (int q = 0; q < 6; ++q) g_sweep_stamps[o + 2 + q] = t_mark[q];
+        for (int q = 0; q < 2; ++q) g_sweep_stamps[o + 2 + q] = t_mark[q];
+    }
+    if ((wave == 2 || wave == 3) && lane == 0 && blockIdx.x < 512) {  // the waves beside wave 6 / the chain
+        const int o = blockIdx.x * 24 + 4 + 2 * (wave - 2);
+        g_sweep_stamps[o + 0] = t_busy;
+        g_sweep_stamps[o + 1] = t_wait;
     }
 #endif
     // last rank-1 update (the loop's final barrier published the delta of its last step)
@@ -370,6 +380,12 @@ __device__ __forceinline__ void la_helper_role(const SweepParams& P, const LaSha
     });
     prepare(0, h_val[0], h_lod[0]);
     prepare(1, h_val[1], h_lod[1]);
+    // Every load of the prologue has landed before the loop is entered: the waits inside the
+    // loop are then those of the steady state (a load still in flight at the loop's entry would
+    // make the compiler's vmcnt bookkeeping wait for the youngest loads in every trip's first steps).
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+        asm volatile("" : "+v"(h_val[u]), "+v"(h_lod[u]), "+v"(h_j[u]), "+v"(n_lod[u]), "+v"(n_j[u]));
     __syncthreads();
 #ifdef LOCUS_STAMPS
     unsigned long long t_busy = 0, t_wait = 0, t_last, t_mark[6] = {0, 0, 0, 0, 0, 0};
@@ -390,14 +406,25 @@ __device__ __forceinline__ void la_helper_role(const SweepParams& P, const LaSha
             constexpr int u2 = (uu + 2) % UN;
             prepare(s + 2, h_val[u2], h_lod[u2]);
             LA_MARK(0);
-            // 2. the slot of step s - 1 now belongs to step s + 7; record of step s + 15
-            h_j[up] = n_j[up];
-            h_lod[up] = n_lod[up];
+            // 2. results of step s - 1: the last use of slot `up` as step s - 1
+            store_step(s - 1, j_prev, v_prev, gmm);
+            // 3. the slot now belongs to step s + 7; record of step s + 15.  The old contents are
+            // dead before the loads are issued and the hand-over of the record is a real move:
+            // otherwise the compiler lets every load of a trip land in a fresh register and
+            // copies them into place at the end of the trip, behind s_waitcnt vmcnt(0) -- the
+            // whole prefetch ring drained once per 8 steps.
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("v_mov_b32 %0, %1" : "=v"(h_j[up]) : "v"(n_j[up]));
+            {
+                int lo_ = __double2loint(n_lod[up]), hi_ = __double2hiint(n_lod[up]), lo2, hi2;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(lo2) : "v"(lo_));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(hi2) : "v"(hi_));
+                h_lod[up] = __hiloint2double(hi2, lo2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             h_val[up] = arr_base[(size_t)h_j[up] * d];
             n_lod[up] = sg[s + 2 * UN - 1 + vz].lod;
             n_j[up] = sg[s + 2 * UN - 1 + vz].j;
-            // 3. results of step s - 1
-            store_step(s - 1, j_prev, v_prev, gmm);
             LA_MARK(1);
             LA_BARRIER();
         });
@@ -486,9 +513,31 @@ __device__ __forceinline__ void la_chain_role(const SweepParams& P, const LaShar
     __syncthreads();  // sums of squares in part[0][c][0..5]
 }
 
-template <int NPL, int CR>
+// Rows per lane of vector wave w under deal DA of a kernel instantiated for NPL.  A wave issues at
+// most one fp64 instruction per 8 cycles and a SIMD one per 4: the step is bounded by the longest
+// wave (8 x its instructions) and by the fullest SIMD (4 x the sum over its waves).  Waves 0, 1, 4, 5
+// share SIMDs 0 and 1 two by two; wave 2 shares SIMD 2 with the state wave, wave 3 shares SIMD 3
+// with the chain wave (both issue less than a vector wave).  DA = 1 gives the four waves of the
+// shared SIMDs one row per lane less: the geometries between two values of NPL, with less work on
+// the fullest SIMDs.  Rows are dealt in wave order.  Measured at n = 2000, d = 500 (sweep, ms):
+//   (6,6,6,6,6,6) 7.04   (5,5,6,6,5,5) 7.04   (5,5,7,5,5,5) 7.17   (5,5,8,4,5,5) 7.25
+// -- the longest wave is the bound: rows moved onto one wave make it longer.  (Before the step
+// put the delta-independent work first the even deal took 7.9 ms and the second one 7.45.)
+constexpr int la_wave_npl(int NPL, int DA, int w)
+{
+    return (DA == 1 && (w & 3) < 2) ? NPL - 1 : NPL;
+}
+constexpr int la_deal_rows(int NPL, int DA)
+{
+    int r = 0;
+    for (int w = 0; w < kLaVec; ++w) r += 64 * la_wave_npl(NPL, DA, w);
+    return r;
+}
+
+template <int NPL, int CR, int DA>
 __global__ void __launch_bounds__(512) logit_la_kernel(const SweepParams P)
 {
+    static_assert((DA == 0 || DA == 1) && la_wave_npl(NPL, DA, 0) >= 1, "a wave without rows");
     constexpr int NK = 2 * CR;
     __shared__ __align__(16) double part[2 * NK * 8];
     __shared__ double dl[2 * CR];
@@ -512,23 +561,33 @@ __global__ void __launch_bounds__(512) logit_la_kernel(const SweepParams P)
     __syncthreads();
 
     const LaShared<CR> L{part, dl, prep, res};
-    if (wave < kLaVec)
-        la_vector_role<NPL, CR>(P, L, wave, lane, k0, nsteps_pad);
-    else if (wave == kLaVec)
+    if (wave < kLaVec) {
+        int rowbase = 0, mine = NPL;
+#pragma unroll
+        for (int w = 0; w < kLaVec; ++w) {
+            if (w < wave) rowbase += 64 * la_wave_npl(NPL, DA, w);
+            if (w == wave) mine = la_wave_npl(NPL, DA, w);
+        }
+        constexpr int NA = la_wave_npl(NPL, DA, 0);
+        if (NA == NPL || mine == NPL)
+            la_vector_role<NPL, CR>(P, L, wave, rowbase, lane, k0, nsteps_pad);
+        else
+            la_vector_role<NA, CR>(P, L, wave, rowbase, lane, k0, nsteps_pad);
+    } else if (wave == kLaVec)
         la_helper_role<CR>(P, L, lane, k0, nsteps, nsteps_pad);
     else
         la_chain_role<CR>(P, L, lane, k0, nsteps, nsteps_pad);
 }
 
-template <int NPL>
+template <int NPL, int DA>
 int launch_npl(const SweepParams& prm, int cr, dim3 grid, hipStream_t st)
 {
     switch (cr) {
-        case 1: hipLaunchKernelGGL((logit_la_kernel<NPL, 1>), grid, dim3(512), 0, st, prm); break;
-        case 2: hipLaunchKernelGGL((logit_la_kernel<NPL, 2>), grid, dim3(512), 0, st, prm); break;
+        case 1: hipLaunchKernelGGL((logit_la_kernel<NPL, 1, DA>), grid, dim3(512), 0, st, prm); break;
+        case 2: hipLaunchKernelGGL((logit_la_kernel<NPL, 2, DA>), grid, dim3(512), 0, st, prm); break;
         case 4:
             if constexpr (NPL <= 6) {
-                hipLaunchKernelGGL((logit_la_kernel<NPL, 4>), grid, dim3(512), 0, st, prm);
+                hipLaunchKernelGGL((logit_la_kernel<NPL, 4, DA>), grid, dim3(512), 0, st, prm);
                 break;
             } else {
                 set_error("logit look-ahead sweep: 4 responses per workgroup need n <= 2304");
@@ -542,6 +601,15 @@ int launch_npl(const SweepParams& prm, int cr, dim3 grid, hipStream_t st)
     return 0;
 }
 
+template <int NPL>
+int launch_deal(const SweepParams& prm, int cr, int da, dim3 grid, hipStream_t st)
+{
+    if constexpr (NPL >= 2) {
+        if (da == 1) return launch_npl<NPL, 1>(prm, cr, grid, st);
+    }
+    return launch_npl<NPL, 0>(prm, cr, grid, st);
+}
+
 }  // namespace
 
 #ifdef LOCUS_STAMPS
@@ -552,28 +620,48 @@ extern "C" int locus_hip_diag_read_la_stamps(unsigned long long* host, int count
 }
 #endif
 
-// Smallest instantiated NPL (1..6, 8) whose workgroup covers n rows (six waves of 64 NPL rows).
-int logit_la_npl_for(int n)
+// Rows a workgroup covers: six vector waves of 64 NPL rows, four of them one row per lane short
+// under the uneven deal.
+static int la_rows(int npl, int da) { return la_deal_rows(npl, da ? 1 : 0); }
+
+// Smallest instantiated geometry (NPL in 1..6, 8; uneven deal or not) whose workgroup covers n
+// rows; NPL = 0: none.  The uneven deal of NPL covers less than the even one and is the faster of
+// the two, so it comes first.
+static void logit_la_geometry_for(int n, int* npl_out, int* da_out)
 {
+    *npl_out = 0;
+    *da_out = 0;
     for (int npl : {1, 2, 3, 4, 5, 6, 8})
-        if (64 * kLaVec * npl >= n) return npl;
-    return 0;
+        for (int da : {1, 0}) {
+            if (da && npl < 2) continue;
+            if (la_rows(npl, da) >= n) {
+                *npl_out = npl;
+                *da_out = da;
+                return;
+            }
+        }
 }
 
 // Largest CR instantiated for n rows (0: n not covered).
 int logit_la_max_cr(int n)
 {
-    const int npl = logit_la_npl_for(n);
+    int npl, da;
+    logit_la_geometry_for(n, &npl, &da);
     return npl == 0 ? 0 : (npl <= 6 ? 4 : 2);
 }
 
-// cfg = {-3, CR, -, NPL}: CR = 0 -> smallest of 1, 2, 4 with one workgroup per CU (4 beyond that);
-// NPL = 0 -> smallest instantiated value that covers n.
+// cfg = {-3, CR, DA, NPL}: CR = 0 -> smallest of 1, 2, 4 with one workgroup per CU (4 beyond
+// that); NPL = 0 -> smallest instantiated geometry that covers n (DA is then chosen too); with an
+// explicit NPL, DA = 1 asks for the uneven deal (waves 0, 1, 4, 5 hold NPL - 1 rows per lane).
 int run_logit_la_sweep(const SweepParams& prm, const SweepConfig& cfg, hipStream_t st)
 {
-    int npl = cfg.G;
-    if (npl == 0) npl = logit_la_npl_for(prm.n);
-    if (npl < 1 || npl > 8 || 64 * kLaVec * npl < prm.n) {
+    int npl = cfg.G, da = cfg.S;
+    if (npl == 0) logit_la_geometry_for(prm.n, &npl, &da);
+    if (da != 0 && da != 1) {
+        set_error("logit look-ahead sweep: the deal (cfg[2]) must be 0 or 1");
+        return LOCUS_HIP_EINVAL;
+    }
+    if (npl < 1 || npl > 8 || (da && npl < 2) || la_rows(npl, da) < prm.n) {
         set_error("logit look-ahead sweep: rows per lane do not cover n (n <= 3072)");
         return LOCUS_HIP_EINVAL;
     }
@@ -589,13 +677,13 @@ int run_logit_la_sweep(const SweepParams& prm, const SweepConfig& cfg, hipStream
     }
     const dim3 grid((unsigned)((prm.d + cr - 1) / cr));
     switch (npl) {
-        case 1: return launch_npl<1>(prm, cr, grid, st);
-        case 2: return launch_npl<2>(prm, cr, grid, st);
-        case 3: return launch_npl<3>(prm, cr, grid, st);
-        case 4: return launch_npl<4>(prm, cr, grid, st);
-        case 5: return launch_npl<5>(prm, cr, grid, st);
-        case 6: return launch_npl<6>(prm, cr, grid, st);
-        case 8: return launch_npl<8>(prm, cr, grid, st);
+        case 1: return launch_deal<1>(prm, cr, da, grid, st);
+        case 2: return launch_deal<2>(prm, cr, da, grid, st);
+        case 3: return launch_deal<3>(prm, cr, da, grid, st);
+        case 4: return launch_deal<4>(prm, cr, da, grid, st);
+        case 5: return launch_deal<5>(prm, cr, da, grid, st);
+        case 6: return launch_deal<6>(prm, cr, da, grid, st);
+        case 8: return launch_deal<8>(prm, cr, da, grid, st);
         default:
             set_error("logit look-ahead sweep: unsupported rows per lane (1..6, 8)");
             return LOCUS_HIP_EUNSUPPORTED;

@@ -65,7 +65,8 @@ def main():
             buf = (ctypes.c_ulonglong * (24 * nwg))()
             fn(buf, 24 * nwg)
             a = np.array(buf, dtype=np.float64).reshape(nwg, 3, 8) / nsteps
-            for ro, nm, names in ((0, "vector wave 0", ["busy", "wait", "->update", "->reduce"]),
+            for ro, nm, names in ((0, "vector wave 0", ["busy", "wait", "->update", "->reduce", "busy2", "wait2",
+                                                       "busy3", "wait3"]),
                                   (2, "wave 6 (duties)", ["busy", "wait", "->stored", "->prepared"]),
                                   (1, "chain", ["busy", "wait", "->U", "->delta"])):
                 med = np.median(a[:, ro, :len(names)], axis=0)

@@ -54,16 +54,17 @@ def test_sweep_geometries_logit(oracle, hip, geom, monkeypatch):
     assert_parity(got, ref, what=f"logit geom {geom}")
 
 
-# logit look-ahead kernel, explicit geometries -3,CR,-,NPL (CR responses per workgroup, six waves
-# of 64 NPL rows): ragged rows and responses, sweeps shorter and longer than the prefetch rings
-LA_GEOMS = [f"-3,{cr},0,{npl}" for npl in (1, 2, 3, 4, 5, 6, 8) for cr in (1, 2, 4)
-            if not (npl == 8 and cr == 4)] + ["-3,0,0,0"]
+# logit look-ahead kernel, explicit geometries -3,CR,DA,NPL (CR responses per workgroup, six waves
+# of 64 NPL rows, four of them one row per lane short when DA = 1): ragged rows and responses,
+# sweeps shorter and longer than the prefetch rings
+LA_GEOMS = [f"-3,{cr},{da},{npl}" for npl in (1, 2, 3, 4, 5, 6, 8) for cr in (1, 2, 4)
+            for da in (0, 1) if not (npl == 8 and cr == 4) and not (npl == 1 and da)] + ["-3,0,0,0"]
 
 
 @pytest.mark.parametrize("geom", LA_GEOMS)
 def test_logit_lookahead_geometries(oracle, hip, geom, monkeypatch):
-    _, cr, _, npl = map(int, geom.split(","))
-    n = 6 * 64 * npl - 5 if npl else 300
+    _, cr, da, npl = map(int, geom.split(","))
+    n = 64 * (6 * npl - 4 * da) - 5 if npl else 300
     p, d = 29, 2 * max(cr, 1) + 1
     inp = inputs_for("logit", n, p, d, seed=5)
     ref = call_variant(oracle, "logit", inp)
