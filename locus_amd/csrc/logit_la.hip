@@ -518,11 +518,12 @@ __device__ __forceinline__ void la_chain_role(const SweepParams& P, const LaShar
 // wave (8 x its instructions) and by the fullest SIMD (4 x the sum over its waves).  Waves 0, 1, 4, 5
 // share SIMDs 0 and 1 two by two; wave 2 shares SIMD 2 with the state wave, wave 3 shares SIMD 3
 // with the chain wave (both issue less than a vector wave).  DA = 1 gives the four waves of the
-// shared SIMDs one row per lane less: the geometries between two values of NPL, with less work on
-// the fullest SIMDs.  Rows are dealt in wave order.  Measured at n = 2000, d = 500 (sweep, ms):
+// shared SIMDs one row per lane less.  Rows are dealt in wave order.  Measured at n = 2000, d = 500
+// (sweep, ms):
 //   (6,6,6,6,6,6) 7.04   (5,5,6,6,5,5) 7.04   (5,5,7,5,5,5) 7.17   (5,5,8,4,5,5) 7.25
-// -- the longest wave is the bound: rows moved onto one wave make it longer.  (Before the step
-// put the delta-independent work first the even deal took 7.9 ms and the second one 7.45.)
+// -- the longest wave is the bound: rows moved onto one wave make it longer, rows taken off the
+// shared SIMDs change nothing.  (Before the step put the delta-independent work first the even
+// deal took 7.9 ms and the second one 7.45.)  DA = 1 is an explicit geometry only.
 constexpr int la_wave_npl(int NPL, int DA, int w)
 {
     return (DA == 1 && (w & 3) < 2) ? NPL - 1 : NPL;
@@ -624,21 +625,18 @@ extern "C" int locus_hip_diag_read_la_stamps(unsigned long long* host, int count
 // under the uneven deal.
 static int la_rows(int npl, int da) { return la_deal_rows(npl, da ? 1 : 0); }
 
-// Smallest instantiated geometry (NPL in 1..6, 8; uneven deal or not) whose workgroup covers n
-// rows; NPL = 0: none.  The uneven deal of NPL covers less than the even one and is the faster of
-// the two, so it comes first.
+// Smallest instantiated NPL (1..6, 8) whose workgroup covers n rows with the even deal; NPL = 0:
+// none.  The uneven deal is never chosen here: it is as fast as the even one of the same NPL (the
+// longest wave binds) and was measured with twice the L2 misses at C4 (FETCH_SIZE 5.3e6 against
+// 2.7e6 KB per sweep); it stays an explicit geometry, cfg = {-3, CR, 1, NPL}.
 static void logit_la_geometry_for(int n, int* npl_out, int* da_out)
 {
     *npl_out = 0;
     *da_out = 0;
     for (int npl : {1, 2, 3, 4, 5, 6, 8})
-        for (int da : {1, 0}) {
-            if (da && npl < 2) continue;
-            if (la_rows(npl, da) >= n) {
-                *npl_out = npl;
-                *da_out = da;
-                return;
-            }
+        if (la_rows(npl, 0) >= n) {
+            *npl_out = npl;
+            return;
         }
 }
 
@@ -651,8 +649,8 @@ int logit_la_max_cr(int n)
 }
 
 // cfg = {-3, CR, DA, NPL}: CR = 0 -> smallest of 1, 2, 4 with one workgroup per CU (4 beyond
-// that); NPL = 0 -> smallest instantiated geometry that covers n (DA is then chosen too); with an
-// explicit NPL, DA = 1 asks for the uneven deal (waves 0, 1, 4, 5 hold NPL - 1 rows per lane).
+// that); NPL = 0 -> smallest instantiated NPL that covers n, even deal; with an explicit NPL,
+// DA = 1 asks for the uneven deal (waves 0, 1, 4, 5 hold NPL - 1 rows per lane).
 int run_logit_la_sweep(const SweepParams& prm, const SweepConfig& cfg, hipStream_t st)
 {
     int npl = cfg.G, da = cfg.S;
