@@ -24,6 +24,7 @@
 // through a ring of the chain wave.
 #include "sweep_kernel.h"
 
+#include <cstddef>
 #include <type_traits>
 #include <utility>
 
@@ -139,21 +140,33 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
     auto load_col = [&](int j, double (&x)[NPL]) {
         const char* col = reinterpret_cast<const char*>(
             P.Xp + (size_t)__builtin_amdgcn_readfirstlane(j) * ld);  // uniform: scalar base
+        // scalar base + 32-bit lane offset: the empty asm keeps the offsets 32 bits wide inside
+        // the loop (hoisted, they become 64-bit pairs and every load a 64-bit vector add)
 #pragma unroll
         for (int i = 0; i + 1 < NPL; i += 2) {
+            asm volatile("" : "+v"(boff[i]));
             const double2 v = *reinterpret_cast<const double2*>(col + boff[i]);
             x[i] = v.x;
             x[i + 1] = v.y;
         }
-        if constexpr (NPL % 2 == 1)
+        if constexpr (NPL % 2 == 1) {
+            asm volatile("" : "+v"(boff[NPL - 1]));
             x[NPL - 1] = *reinterpret_cast<const double*>(col + boff[NPL - 1]);
+        }
     };
     // step records through VECTOR loads (lane-uniform address): a scalar load would share
     // lgkmcnt with the LDS traffic of the step, and every LDS wait would then also wait for a
     // K$ miss; vmcnt retires in order behind the ring, several steps later
-    int vz = 0;
+    unsigned vz = 0;
     asm volatile("" : "+v"(vz));
     const StepRec* const sg = P.steps;
+    // (uniform record address in SGPRs + a 32-bit zero the compiler cannot see through: a vector
+    // load with no address arithmetic on the vector ALU)
+    auto rec_j = [&](int step) {
+        asm volatile("" : "+v"(vz));
+        return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(sg + step) + vz +
+                                             offsetof(StepRec, j));
+    };
     // wave totals of p_c = sum_i x_i r_ci and c_c = sum_i x_i xw_ci (this wave's rows) -> part[par]
     auto reduce_write = [&](const double (&pv)[CR], const double (&cv)[CR], int par) {
         double* pb = L.part + par * NK * 8 + wave;
@@ -178,8 +191,8 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
     int jv[D];
     lfor<D>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        load_col(sg[u + vz].j, xr[u]);
-        jv[u] = sg[u + D + vz].j;
+        load_col(rec_j(u), xr[u]);
+        jv[u] = rec_j(u + D);
     });
 #pragma unroll
     for (int cc = 0; cc < CR; ++cc)
@@ -244,7 +257,7 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
             LA_MARK(1);
             // slot u is free: column of step s + D, index of step s + 2 D
             load_col(jv[u], xr[u]);
-            jv[u] = sg[s + 2 * D + vz].j;
+            jv[u] = rec_j(s + 2 * D);
             LA_BARRIER();
         });
     }
