@@ -73,6 +73,24 @@ def test_logit_lookahead_geometries(oracle, hip, geom, monkeypatch):
     assert_parity(got, ref, what=f"logit look-ahead geom {geom}")
 
 
+@pytest.mark.parametrize("geom", ["-3,2,2,6", "-3,2,1,1", "-3,3,0,2", "-3,4,0,8", "-3,1,0,1", "-3,1,1,2",
+                                  "-3,1,0,7"])
+def test_logit_lookahead_bad_geometry_is_refused(hip, geom, monkeypatch):
+    """A look-ahead geometry that does not exist (deal other than 0 / 1, uneven deal of one row per
+    lane, 3 responses per workgroup, 4 with NPL = 8, no NPL = 7) or does not cover n (6 * 64 rows
+    and 4 * 64 + 2 * 128 rows for n = 600) is an error before any launch: the caller's matrices are untouched."""
+    from locus_amd._lib import LocusHipError
+    inp = inputs_for("logit", 600, 17, 5, seed=2)
+    before = {k: np.array(inp[k], copy=True) for k in ("gam_vb", "beta_vb", "mat_x_m1", "mu_beta_vb")}
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", geom)
+    with pytest.raises(LocusHipError) as ei:
+        call_variant(hip, "logit", inp)
+    assert ei.value.code in (-1, -2), ei.value          # EINVAL / EUNSUPPORTED
+    assert "look-ahead" in str(ei.value)
+    for k, v in before.items():
+        assert np.array_equal(v, inp[k]), k
+
+
 @pytest.mark.parametrize("shape", [(100, 1, 3), (100, 2, 1), (64, 7, 9), (450, 8, 2), (449, 9, 5),
                                    (1000, 203, 41)])
 def test_logit_lookahead_short_and_long_sweeps(oracle, hip, shape, monkeypatch):
