@@ -10,18 +10,20 @@
 // the wave reduction, a barrier, the element-wise chain and the rank-1 update in sequence
 // (~2500 cycles at the C4 shape).  Here the row work runs ONE STEP AHEAD of the chain:
 //     U_{s+1} = X_{s+1}' R^(s) + (X_{s+1}' (X_s o W2)) delta_s = p_{s+1} + c_{s+1} delta_s
-// so while the chain wave evaluates step s, the seven vector waves apply delta_{s-1}, form
+// so while the chain wave evaluates step s, the six vector waves apply delta_{s-1}, form
 // X_s o W2 and reduce p_{s+1}, c_{s+1} over their rows.  One barrier per step; the step time is
-// the longer of the chain (LDS read of 2 x 8 partials, ~40 dependent fp64 instructions) and the
-// vector side (~45 FMAs, one transposing wave reduction), instead of their sum.
+// the longer of the chain (LDS read of 2 x 6 partials, ~60 fp64 instructions) and the vector side
+// (4 fp64 instructions per row register and response, one transposing wave reduction of 21
+// instructions, the column prefetch), instead of their sum.  A wave issues one fp64 instruction
+// per ~8 cycles whatever their dependences: a role's time is its instruction count.
 //
-// Geometry: workgroup = 8 waves = 7 vector waves + 1 chain wave, CR in {1, 2, 4} responses per
-// workgroup (one workgroup per CU: d_loc <= CR * CUs), lane l of vector wave v holds NPL rows of
-// the wave's slice (consecutive rows in pairs: 16-byte loads) of R, W2 and the current X o W2 in
-// VGPRs for the whole sweep.
-// X columns are read straight from the packed matrix (coalesced 1 KB rows per wave) through a
-// register ring XD steps ahead; per-(j, k) state (beta_old, sig2_beta, xwx, log sig2_beta / 2)
-// through a ring of the chain wave.
+// Geometry: workgroup = 8 waves = 6 vector waves + the state wave (6) + the chain wave (7), CR in
+// {1, 2, 4} responses per workgroup (one workgroup per CU: d_loc <= CR * CUs), lane l of vector
+// wave v holds NPL rows of the wave's slice (consecutive rows in pairs: 16-byte loads) of R, W2 and
+// the current X o W2 in VGPRs for the whole sweep.
+// X columns are read straight from the packed matrix (scalar base + 32-bit lane offsets, coalesced
+// 1 KB rows per wave) through a register ring D steps ahead; per-(j, k) state (beta_old, sig2_beta,
+// xwx, log sig2_beta / 2) through a ring of the state wave, which also stores the results.
 #include "sweep_kernel.h"
 
 #include <cstddef>
