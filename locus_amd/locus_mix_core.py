@@ -185,7 +185,9 @@ class MixEngine(IdentityEngine):
         stats = t.cat([cols, rss.reshape(1, d)], dim=0).cpu().numpy()
         self.host.set_initial(stats, rs_gam)
 
-    def iterate(self, shuffled_ind, alpha_order=None):
+    def iterate(self, shuffled_ind, alpha_order=None, before_readback=None):
+        """`before_readback()`: host work of the caller (the next sweep order) once the kernels of
+        this iteration are queued, before the host blocks on the read-back."""
         dv, t = self.dv, self.torch
         n, d = self.n, self.d_loc
         prm = self.host.begin_iteration()
@@ -200,7 +202,10 @@ class MixEngine(IdentityEngine):
         dv.residual(self.W, self.R, self.Zmu, out=self.M)
         rs_gam, ent = dv.gamma_rows(self.state[0], self.p, d, eps=self.host.ent_eps)
         ey_bin = self._update_W(True)
-        h = t.cat([self.stats.reshape(-1), ent.sum().reshape(1), self.alpha.reshape(-1)]).cpu().numpy()
+        h_dev = t.cat([self.stats.reshape(-1), ent.sum().reshape(1), self.alpha.reshape(-1)])
+        if before_readback is not None:
+            before_readback()
+        h = h_dev.cpu().numpy()
         self.sweeper.status()
         return self.host.end_iteration(h[: 4 * d].reshape(4, d), rs_gam, float(h[4 * d]),
                                        h[4 * d + 1:], ey_bin, self.zz)
@@ -292,13 +297,19 @@ def locus_mix_core_(Y, X, Z, ind_bin, list_hyper, gam_vb, alpha_vb, mu_beta_vb, 
     eng.initialise()
 
     converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
+    nxt = {}
+    draw = lambda i: (np.ascontiguousarray(perm_fn(i), dtype=np.float64), alpha_perm_fn(i))  # noqa: E731
     while (not converged) and it < maxit:                                # :53
         lb_old = lb_new
         it += 1
         if verbose and (it == 1 or it % 5 == 0):
             print(f"Iteration {it}... ")
-        ind = np.ascontiguousarray(perm_fn(it), dtype=np.float64)
-        lb_new = eng.iterate(ind, alpha_order=alpha_perm_fn(it))
+        ind, a_order = nxt.pop(it) if it in nxt else draw(it)
+
+        def draw_next(it=it):                 # while the GPU runs this iteration
+            if it < maxit:
+                nxt[it + 1] = draw(it + 1)
+        lb_new = eng.iterate(ind, alpha_order=a_order, before_readback=draw_next)
         if trace is not None:
             trace.append((it, lb_new))
         if verbose and (it == 1 or it % 5 == 0):

@@ -150,7 +150,9 @@ class ZEngine(IdentityEngine):
         stats = t.cat([cols, rss.reshape(1, d)], dim=0).cpu().numpy()
         self.host.set_initial(stats, rs_gam)
 
-    def iterate(self, shuffled_ind, c=1.0, with_elbo=True, alpha_order=None):
+    def iterate(self, shuffled_ind, c=1.0, with_elbo=True, alpha_order=None, before_readback=None):
+        """`before_readback()`: host work of the caller (the next sweep order) once the kernels of
+        this iteration are queued, before the host blocks on the read-back."""
         dv, t = self.dv, self.torch
         n, d = self.n, self.d_loc
         prm = self.host.begin_iteration(c)
@@ -167,7 +169,10 @@ class ZEngine(IdentityEngine):
                                     eps=self.host.ent_eps if with_elbo else None)
         tail = ent.sum().reshape(1) if with_elbo else t.zeros(1, dtype=t.float64,
                                                               device=self.device)
-        h = t.cat([self.stats.reshape(-1), tail, self.alpha.reshape(-1)]).cpu().numpy()
+        h_dev = t.cat([self.stats.reshape(-1), tail, self.alpha.reshape(-1)])
+        if before_readback is not None:
+            before_readback()
+        h = h_dev.cpu().numpy()
         self.sweeper.status()
         stats = h[: 4 * d].reshape(4, d)
         return self.host.end_iteration(stats, rs_gam, float(h[4 * d]), h[4 * d + 1:], c, with_elbo)
@@ -236,13 +241,20 @@ def locus_z_core_(Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_
         c = float(ladder[0])
 
     converged, lb_new, lb_old, it = False, -np.inf, -np.inf, 0
+    nxt = {}
+    draw = lambda i: (np.ascontiguousarray(perm_fn(i), dtype=np.float64), alpha_perm_fn(i))  # noqa: E731
     while (not converged) and it < maxit:                                # :49
         lb_old = lb_new
         it += 1
         if verbose and (it == 1 or it % 5 == 0):
             print(f"Iteration {it}... ")
-        ind = np.ascontiguousarray(perm_fn(it), dtype=np.float64)
-        lb = eng.iterate(ind, c, with_elbo=not annealing, alpha_order=alpha_perm_fn(it))
+        ind, a_order = nxt.pop(it) if it in nxt else draw(it)
+
+        def draw_next(it=it):                 # while the GPU runs this iteration
+            if it < maxit:
+                nxt[it + 1] = draw(it + 1)
+        lb = eng.iterate(ind, c, with_elbo=not annealing, alpha_order=a_order,
+                         before_readback=draw_next)
         if annealing:                                                    # :214-228
             c = float(ladder[it]) if it < len(ladder) else 1.0
             if np.isclose(c, 1.0, rtol=1.5e-8, atol=0):
