@@ -111,7 +111,7 @@ KERNEL_NOTE = {
                 "mfma_sweep1_kernel: one tile of 16 responses per cluster of 1-3 CUs)",
     "struct": "coreStructLoop sweep = block packing + mfma_sweep1_kernel (one tile of 16 responses "
               "per cluster of 1-3 CUs), per-covariate prior term log(1 - Phi) - log Phi",
-    "logit": "coreLogitLoop sweep = logit_la_kernel<NPL,CR,DA> (one step of look-ahead, dedicated "
+    "logit": "coreLogitLoop sweep = logit_la_kernel<NPL,CR,R16> (one step of look-ahead, dedicated "
              "chain wave; vector fp64)",
 }
 ORACLE_ROUTINE = {"identity": "coreLoop (src/coreLoop.cpp:19-54)",

@@ -13,9 +13,11 @@
 // so while the chain wave evaluates step s, the six vector waves apply delta_{s-1}, form
 // X_s o W2 and reduce p_{s+1}, c_{s+1} over their rows.  One barrier per step; the step time is
 // the longer of the chain (LDS read of 2 x 6 partials, ~60 fp64 instructions) and the vector side
-// (4 fp64 instructions per row register and response, one transposing wave reduction of 21
-// instructions, the column prefetch), instead of their sum.  A wave issues one fp64 instruction
-// per ~8 cycles whatever their dependences: a role's time is its instruction count.
+// (4 fp64 instructions per row register and response, one transposing wave reduction, the column
+// prefetch), instead of their sum.  A wave issues one fp64 instruction per ~8 cycles whatever
+// their dependences: a role's time is its instruction count.  The reduction is 21 instructions
+// per vector wave, or 9 with the last four levels done once on the chain wave (R16, where the
+// vector waves bind).
 //
 // Geometry: workgroup = 8 waves = 6 vector waves + the state wave (6) + the chain wave (7), CR in
 // {1, 2, 4} responses per workgroup (one workgroup per CU: d_loc <= CR * CUs), lane l of vector
@@ -88,13 +90,38 @@ constexpr int la_depth()
 template <int CR>
 struct LaShared {
     double* part;  // [parity][value 0..2CR-1][wave slot 0..7]  (slots 6, 7 stay zero)
+    double* p16;   // R16: [parity][wave 0..5][value slot 0..NV-1][16]: totals over 4 lanes, the
+                   // chain wave adds up the six waves and the 16 entries of a slot
     double* dl;    // [parity][c]           delta of the last step
     double* prep;  // [S % 4][c]{xb, a0, s2, bo}
     double* res;   // [s % 8][c]{gam, mu}
 };
 
 // ---- vector waves 0..5: rows of R, W2, X o W2 -------------------------------------------------
-template <int NPL, int CR>
+// Value slots of p16: CR <= 2 -> {p_0, p_1, c_0, c_1} (c sits 32 lanes above p on the chain wave),
+// CR = 4 -> {p_0..p_3, c_0..c_3}
+template <int CR>
+constexpr int la_slots() { return CR <= 2 ? 4 : 8; }
+
+// first two levels of reduce4: lane l holds the sum over lanes l % 16 + {0, 16, 32, 48} of the value
+// its DPP row ends up with
+__device__ __forceinline__ double reduce4_rows(double a0, double a1, double a2, double a3)
+{
+    return swap16_add(swap32_add(a0, a1), swap32_add(a2, a3));
+}
+
+// lanes < 32: the value of lane + 32 (v_permlane32_swap exchanges lanes 32..63 of its first operand
+// with lanes 0..31 of its second and returns both)
+__device__ __forceinline__ double upper_half(double v)
+{
+    const u32x2 lo = __builtin_amdgcn_permlane32_swap((u32)__double2loint(v), (u32)__double2loint(v),
+                                                      false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane32_swap((u32)__double2hiint(v), (u32)__double2hiint(v),
+                                                      false, false);
+    return mk_double(hi.y, lo.y);
+}
+
+template <int NPL, int CR, int R16>
 __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaShared<CR>& L,
                                                const int wave, const int rowbase, const int lane,
                                                const int k0, const int nsteps_pad)
@@ -128,6 +155,7 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
     // of the permlane swaps)
     const int val = (int)(reduce4(0.0, 1.0 / 64.0, 2.0 / 64.0, 3.0 / 64.0) + 0.5);
     const bool pw = (lane & 15) == 0;
+    constexpr int NV = la_slots<CR>();
 
     // byte offsets of this lane's rows inside a packed column; rows past the column's padding
     // (the workgroup may cover more than ld rows) are clamped: r = w = 0 there, so whatever
@@ -171,6 +199,20 @@ __device__ __forceinline__ void la_vector_role(const SweepParams& P, const LaSha
     };
     // wave totals of p_c = sum_i x_i r_ci and c_c = sum_i x_i xw_ci (this wave's rows) -> part[par]
     auto reduce_write = [&](const double (&pv)[CR], const double (&cv)[CR], int par) {
+        if constexpr (R16) {
+            // two levels here (9 instructions), the other four on the chain wave: every lane
+            // stores its row's value, no lane mask
+            double* pb = L.p16 + ((par * kLaVec + wave) * NV + val) * 16 + (lane & 15);
+            if constexpr (CR == 1) {
+                pb[0] = reduce4_rows(pv[0], 0.0, cv[0], 0.0);
+            } else if constexpr (CR == 2) {
+                pb[0] = reduce4_rows(pv[0], pv[1], cv[0], cv[1]);
+            } else {
+                pb[0] = reduce4_rows(pv[0], pv[1], pv[2], pv[3]);
+                pb[4 * 16] = reduce4_rows(cv[0], cv[1], cv[2], cv[3]);
+            }
+            return;
+        }
         double* pb = L.part + par * NK * 8 + wave;
         if constexpr (CR == 1) {
             const double u = reduce4(pv[0], cv[0], 0.0, 0.0);
@@ -467,17 +509,28 @@ __device__ __forceinline__ void la_helper_role(const SweepParams& P, const LaSha
     }
 }
 
-// ---- chain wave: one response per lane (lanes < CR) -------------------------------------------
+// ---- chain wave ------------------------------------------------------------------------------
 // No global access at all: operands come prepared through `prep`, results leave through `dl`
 // (delta, read by every vector wave) and `res` (gam, mu for wave 6).
-template <int CR>
+// R16 = 0: one response per lane (lanes < CR), the vector waves deliver wave totals.
+// R16 = 1: the vector waves stop their reduction at 16 entries per value (reduce4_rows) and this
+// wave finishes it: lane l adds up the six waves' entry l % 16 of value slot l / 16 and the four
+// DPP levels give every lane of row l / 16 that value's total; response c then lives in row c
+// (all 16 lanes compute it, lane 16 c writes).  12 cross-lane instructions leave each of the six
+// vector waves for 19 here (5 adds over the waves instead of 10: the four values are summed side
+// by side) -- where the vector waves bind (n large), not where the chain does.
+template <int CR, int R16>
 __device__ __forceinline__ void la_chain_role(const SweepParams& P, const LaShared<CR>& L,
                                               const int lane, const int k0, const int nsteps,
                                               const int nsteps_pad)
 {
     constexpr int NK = 2 * CR;
-    const int c = lane < CR ? lane : 0;
-    const bool valid = (lane < CR) && (k0 + c < P.d);
+    constexpr int NV = la_slots<CR>();
+    const int row = lane >> 4;
+    const int c = R16 ? (row < CR ? row : 0) : (lane < CR ? lane : 0);
+    const bool mine = R16 ? (row < CR) : (lane < CR);          // lanes that run response c
+    const bool writer = R16 ? (mine && (lane & 15) == 0) : mine;
+    const bool valid = mine && (k0 + c < P.d);
     double dprev = 0.0;
     // the chain is the critical path of every step: win the issue arbitration against the vector
     // wave that shares this SIMD
@@ -489,16 +542,39 @@ __device__ __forceinline__ void la_chain_role(const SweepParams& P, const LaShar
 #endif
     for (int s = 0; s < nsteps_pad; ++s) {
         const bool act = valid && (s < nsteps);
-        // U = sum_w p_w + (sum_w c_w) delta_{s-1}
-        const double2* pp = reinterpret_cast<const double2*>(L.part + ((s & 1) * NK + c) * 8);
-        const double2* cp = reinterpret_cast<const double2*>(L.part + ((s & 1) * NK + CR + c) * 8);
         const double2* qp = reinterpret_cast<const double2*>(L.prep + ((s & 3) * CR + c) * 4);
-        const double2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
-        const double2 p0 = pp[0], p1 = pp[1], p2 = pp[2];
-        const double2 q0 = qp[0], q1 = qp[1];
-        const double cs = ((c0.x + c0.y) + (c1.x + c1.y)) + (c2.x + c2.y);
-        const double ps = ((p0.x + p0.y) + (p1.x + p1.y)) + (p2.x + p2.y);
-        const double U = fma(cs, dprev, ps);
+        // U = sum_w p_w + (sum_w c_w) delta_{s-1}
+        double U;
+        double2 q0, q1;
+        if constexpr (R16) {
+            const double* src = L.p16 + (s & 1) * (kLaVec * NV * 16) + lane;   // slot row, entry lane % 16
+            double t[kLaVec], t2[kLaVec];
+#pragma unroll
+            for (int w = 0; w < kLaVec; ++w) t[w] = src[w * NV * 16];
+            if constexpr (CR == 4) {
+#pragma unroll
+                for (int w = 0; w < kLaVec; ++w) t2[w] = src[w * NV * 16 + 64];
+            }
+            q0 = qp[0];
+            q1 = qp[1];
+            const double ps = row_allreduce(((t[0] + t[1]) + (t[2] + t[3])) + (t[4] + t[5]));
+            double cs;
+            if constexpr (CR == 4)
+                cs = row_allreduce(((t2[0] + t2[1]) + (t2[2] + t2[3])) + (t2[4] + t2[5]));
+            else
+                cs = upper_half(ps);                    // rows 2, 3 hold c_0, c_1
+            U = fma(cs, dprev, ps);
+        } else {
+            const double2* pp = reinterpret_cast<const double2*>(L.part + ((s & 1) * NK + c) * 8);
+            const double2* cp = reinterpret_cast<const double2*>(L.part + ((s & 1) * NK + CR + c) * 8);
+            const double2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+            const double2 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+            q0 = qp[0];
+            q1 = qp[1];
+            const double cs = ((c0.x + c0.y) + (c1.x + c1.y)) + (c2.x + c2.y);
+            const double ps = ((p0.x + p0.y) + (p1.x + p1.y)) + (p2.x + p2.y);
+            U = fma(cs, dprev, ps);
+        }
         LA_MARK(0);
         const double bo = q1.y;
         const double dot = q0.x + U;   // xwx * beta_old + U   (coreLoop.cpp:121)
@@ -509,9 +585,9 @@ __device__ __forceinline__ void la_chain_role(const SweepParams& P, const LaShar
         const double gm = div_1to2((a >= 0.0) ? e : 1.0, 1.0 + e);
         const double bn = m * gm;                                // :127
         const double delta = act ? (bo - bn) : 0.0;
-        if (lane < CR) {
-            L.dl[(s & 1) * CR + lane] = delta;
-            *reinterpret_cast<double2*>(L.res + ((s & 7) * CR + lane) * 2) = make_double2(gm, m);
+        if (writer) {
+            L.dl[(s & 1) * CR + c] = delta;
+            *reinterpret_cast<double2*>(L.res + ((s & 7) * CR + c) * 2) = make_double2(gm, m);
         }
         dprev = delta;
         LA_MARK(1);
@@ -528,34 +604,19 @@ __device__ __forceinline__ void la_chain_role(const SweepParams& P, const LaShar
     __syncthreads();  // sums of squares in part[0][c][0..5]
 }
 
-// Rows per lane of vector wave w under deal DA of a kernel instantiated for NPL.  A wave issues at
-// most one fp64 instruction per 8 cycles and a SIMD one per 4: the step is bounded by the longest
-// wave (8 x its instructions) and by the fullest SIMD (4 x the sum over its waves).  Waves 0, 1, 4, 5
-// share SIMDs 0 and 1 two by two; wave 2 shares SIMD 2 with the state wave, wave 3 shares SIMD 3
-// with the chain wave (both issue less than a vector wave).  DA = 1 gives the four waves of the
-// shared SIMDs one row per lane less.  Rows are dealt in wave order.  Measured at n = 2000, d = 500
-// (sweep, ms):
-//   (6,6,6,6,6,6) 7.04   (5,5,6,6,5,5) 7.04   (5,5,7,5,5,5) 7.17   (5,5,8,4,5,5) 7.25
-// -- the longest wave is the bound: rows moved onto one wave make it longer, rows taken off the
-// shared SIMDs change nothing.  (Before the step put the delta-independent work first the even
-// deal took 7.9 ms and the second one 7.45.)  DA = 1 is an explicit geometry only.
-constexpr int la_wave_npl(int NPL, int DA, int w)
-{
-    return (DA == 1 && (w & 3) < 2) ? NPL - 1 : NPL;
-}
-constexpr int la_deal_rows(int NPL, int DA)
-{
-    int r = 0;
-    for (int w = 0; w < kLaVec; ++w) r += 64 * la_wave_npl(NPL, DA, w);
-    return r;
-}
-
-template <int NPL, int CR, int DA>
+// A wave issues at most one fp64 instruction per ~8 cycles and a SIMD one per 4: the step is
+// bounded by the longest wave and by the fullest SIMD.  Waves 0, 1, 4, 5 share SIMDs 0 and 1 two by
+// two; wave 2 shares SIMD 2 with the state wave, wave 3 shares SIMD 3 with the chain wave.  Uneven
+// deals of the rows over the waves were measured at n = 2000, d = 500 (sweep, ms; rows per lane of
+// waves 0..5):  (6,6,6,6,6,6) 7.04   (5,5,6,6,5,5) 7.04, with twice the L2 misses
+// (5,5,7,5,5,5) 7.17   (5,5,8,4,5,5) 7.25  -- the longest wave binds; the deal stays even.
+template <int NPL, int CR, int R16>
 __global__ void __launch_bounds__(512) logit_la_kernel(const SweepParams P)
 {
-    static_assert((DA == 0 || DA == 1) && la_wave_npl(NPL, DA, 0) >= 1, "a wave without rows");
     constexpr int NK = 2 * CR;
+    constexpr int NV = la_slots<CR>();
     __shared__ __align__(16) double part[2 * NK * 8];
+    __shared__ __align__(16) double p16[R16 ? 2 * kLaVec * NV * 16 : 2];
     __shared__ double dl[2 * CR];
     __shared__ __align__(16) double prep[4 * CR * 4];
     __shared__ __align__(16) double res[8 * CR * 2];
@@ -574,36 +635,29 @@ __global__ void __launch_bounds__(512) logit_la_kernel(const SweepParams P)
 
     if (tid < 2 * NK * 8) part[tid] = 0.0;
     if (tid < 2 * CR) dl[tid] = 0.0;
+    if constexpr (R16) {
+        for (int i = tid; i < 2 * kLaVec * NV * 16; i += 512) p16[i] = 0.0;   // slots no wave writes (CR = 1)
+    }
     __syncthreads();
 
-    const LaShared<CR> L{part, dl, prep, res};
-    if (wave < kLaVec) {
-        int rowbase = 0, mine = NPL;
-#pragma unroll
-        for (int w = 0; w < kLaVec; ++w) {
-            if (w < wave) rowbase += 64 * la_wave_npl(NPL, DA, w);
-            if (w == wave) mine = la_wave_npl(NPL, DA, w);
-        }
-        constexpr int NA = la_wave_npl(NPL, DA, 0);
-        if (NA == NPL || mine == NPL)
-            la_vector_role<NPL, CR>(P, L, wave, rowbase, lane, k0, nsteps_pad);
-        else
-            la_vector_role<NA, CR>(P, L, wave, rowbase, lane, k0, nsteps_pad);
-    } else if (wave == kLaVec)
+    const LaShared<CR> L{part, p16, dl, prep, res};
+    if (wave < kLaVec)
+        la_vector_role<NPL, CR, R16>(P, L, wave, wave * NPL * 64, lane, k0, nsteps_pad);
+    else if (wave == kLaVec)
         la_helper_role<CR>(P, L, lane, k0, nsteps, nsteps_pad);
     else
-        la_chain_role<CR>(P, L, lane, k0, nsteps, nsteps_pad);
+        la_chain_role<CR, R16>(P, L, lane, k0, nsteps, nsteps_pad);
 }
 
-template <int NPL, int DA>
+template <int NPL, int R16>
 int launch_npl(const SweepParams& prm, int cr, dim3 grid, hipStream_t st)
 {
     switch (cr) {
-        case 1: hipLaunchKernelGGL((logit_la_kernel<NPL, 1, DA>), grid, dim3(512), 0, st, prm); break;
-        case 2: hipLaunchKernelGGL((logit_la_kernel<NPL, 2, DA>), grid, dim3(512), 0, st, prm); break;
+        case 1: hipLaunchKernelGGL((logit_la_kernel<NPL, 1, R16>), grid, dim3(512), 0, st, prm); break;
+        case 2: hipLaunchKernelGGL((logit_la_kernel<NPL, 2, R16>), grid, dim3(512), 0, st, prm); break;
         case 4:
             if constexpr (NPL <= 6) {
-                hipLaunchKernelGGL((logit_la_kernel<NPL, 4, DA>), grid, dim3(512), 0, st, prm);
+                hipLaunchKernelGGL((logit_la_kernel<NPL, 4, R16>), grid, dim3(512), 0, st, prm);
                 break;
             } else {
                 set_error("logit look-ahead sweep: 4 responses per workgroup need n <= 2304");
@@ -618,12 +672,9 @@ int launch_npl(const SweepParams& prm, int cr, dim3 grid, hipStream_t st)
 }
 
 template <int NPL>
-int launch_deal(const SweepParams& prm, int cr, int da, dim3 grid, hipStream_t st)
+int launch_red(const SweepParams& prm, int cr, int r16, dim3 grid, hipStream_t st)
 {
-    if constexpr (NPL >= 2) {
-        if (da == 1) return launch_npl<NPL, 1>(prm, cr, grid, st);
-    }
-    return launch_npl<NPL, 0>(prm, cr, grid, st);
+    return r16 ? launch_npl<NPL, 1>(prm, cr, grid, st) : launch_npl<NPL, 0>(prm, cr, grid, st);
 }
 
 }  // namespace
@@ -636,45 +687,42 @@ extern "C" int locus_hip_diag_read_la_stamps(unsigned long long* host, int count
 }
 #endif
 
-// Rows a workgroup covers: six vector waves of 64 NPL rows, four of them one row per lane short
-// under the uneven deal.
-static int la_rows(int npl, int da) { return la_deal_rows(npl, da ? 1 : 0); }
-
-// Smallest instantiated NPL (1..6, 8) whose workgroup covers n rows with the even deal; NPL = 0:
-// none.  The uneven deal is never chosen here: it is as fast as the even one of the same NPL (the
-// longest wave binds) and was measured with twice the L2 misses at C4 (FETCH_SIZE 5.3e6 against
-// 2.7e6 KB per sweep); it stays an explicit geometry, cfg = {-3, CR, 1, NPL}.
-static void logit_la_geometry_for(int n, int* npl_out, int* da_out)
+// Smallest instantiated NPL (1..6, 8) whose workgroup covers n rows (six waves of 64 NPL rows).
+static int logit_la_npl_for(int n)
 {
-    *npl_out = 0;
-    *da_out = 0;
     for (int npl : {1, 2, 3, 4, 5, 6, 8})
-        if (la_rows(npl, 0) >= n) {
-            *npl_out = npl;
-            return;
-        }
+        if (64 * kLaVec * npl >= n) return npl;
+    return 0;
 }
 
 // Largest CR instantiated for n rows (0: n not covered).
 int logit_la_max_cr(int n)
 {
-    int npl, da;
-    logit_la_geometry_for(n, &npl, &da);
+    const int npl = logit_la_npl_for(n);
     return npl == 0 ? 0 : (npl <= 6 ? 4 : 2);
 }
 
-// cfg = {-3, CR, DA, NPL}: CR = 0 -> smallest of 1, 2, 4 with one workgroup per CU (4 beyond
-// that); NPL = 0 -> smallest instantiated NPL that covers n, even deal; with an explicit NPL,
-// DA = 1 asks for the uneven deal (waves 0, 1, 4, 5 hold NPL - 1 rows per lane).
+// Who finishes the reduction of the partial sums (1: the chain wave), as measured for every
+// geometry at p = 20 000 (scripts/la_red_sweep.sh): the chain wave wherever the
+// vector waves bind the step -- CR = 4 always (two reductions per step: -1 to -17 %), CR = 2 from
+// 3 rows per lane (-5 to -13 %; +1 to +7 % below), CR = 1 from 5 (-1 to -4 %; +3 to +7 % below).
+static int logit_la_r16_for(int npl, int cr)
+{
+    return cr == 4 || (cr == 2 && npl >= 3) || (cr == 1 && npl >= 5);
+}
+
+// cfg = {-3, CR, RED, NPL}: CR = 0 -> smallest of 1, 2, 4 with one workgroup per CU (4 beyond
+// that); NPL = 0 -> smallest instantiated NPL that covers n; RED = 0 -> the reduction is finished
+// where it was measured faster, 1 -> by the vector waves, 2 -> by the chain wave.
 int run_logit_la_sweep(const SweepParams& prm, const SweepConfig& cfg, hipStream_t st)
 {
-    int npl = cfg.G, da = cfg.S;
-    if (npl == 0) logit_la_geometry_for(prm.n, &npl, &da);
-    if (da != 0 && da != 1) {
-        set_error("logit look-ahead sweep: the deal (cfg[2]) must be 0 or 1");
+    int npl = cfg.G;
+    if (npl == 0) npl = logit_la_npl_for(prm.n);
+    if (cfg.S < 0 || cfg.S > 2) {
+        set_error("logit look-ahead sweep: the reduction mode (cfg[2]) must be 0, 1 or 2");
         return LOCUS_HIP_EINVAL;
     }
-    if (npl < 1 || npl > 8 || (da && npl < 2) || la_rows(npl, da) < prm.n) {
+    if (npl < 1 || npl > 8 || 64 * kLaVec * npl < prm.n) {
         set_error("logit look-ahead sweep: rows per lane do not cover n (n <= 3072)");
         return LOCUS_HIP_EINVAL;
     }
@@ -684,19 +732,20 @@ int run_logit_la_sweep(const SweepParams& prm, const SweepConfig& cfg, hipStream
         cr = prm.d <= cus ? 1 : (prm.d <= 2 * cus ? 2 : 4);
         if (cr > logit_la_max_cr(prm.n)) cr = logit_la_max_cr(prm.n);
     }
+    const int r16 = cfg.S == 0 ? logit_la_r16_for(npl, cr) : cfg.S - 1;
     if (prm.ld < prm.n || (prm.ld & 127) != 0 || (reinterpret_cast<uintptr_t>(prm.Xp) & 15) != 0) {
         set_error("logit look-ahead sweep: packed X needs ld >= n, ld % 128 == 0, 16-byte alignment");
         return LOCUS_HIP_EINVAL;
     }
     const dim3 grid((unsigned)((prm.d + cr - 1) / cr));
     switch (npl) {
-        case 1: return launch_deal<1>(prm, cr, da, grid, st);
-        case 2: return launch_deal<2>(prm, cr, da, grid, st);
-        case 3: return launch_deal<3>(prm, cr, da, grid, st);
-        case 4: return launch_deal<4>(prm, cr, da, grid, st);
-        case 5: return launch_deal<5>(prm, cr, da, grid, st);
-        case 6: return launch_deal<6>(prm, cr, da, grid, st);
-        case 8: return launch_deal<8>(prm, cr, da, grid, st);
+        case 1: return launch_red<1>(prm, cr, r16, grid, st);
+        case 2: return launch_red<2>(prm, cr, r16, grid, st);
+        case 3: return launch_red<3>(prm, cr, r16, grid, st);
+        case 4: return launch_red<4>(prm, cr, r16, grid, st);
+        case 5: return launch_red<5>(prm, cr, r16, grid, st);
+        case 6: return launch_red<6>(prm, cr, r16, grid, st);
+        case 8: return launch_red<8>(prm, cr, r16, grid, st);
         default:
             set_error("logit look-ahead sweep: unsupported rows per lane (1..6, 8)");
             return LOCUS_HIP_EUNSUPPORTED;

@@ -54,17 +54,17 @@ def test_sweep_geometries_logit(oracle, hip, geom, monkeypatch):
     assert_parity(got, ref, what=f"logit geom {geom}")
 
 
-# logit look-ahead kernel, explicit geometries -3,CR,DA,NPL (CR responses per workgroup, six waves
-# of 64 NPL rows, four of them one row per lane short when DA = 1): ragged rows and responses,
-# sweeps shorter and longer than the prefetch rings
-LA_GEOMS = [f"-3,{cr},{da},{npl}" for npl in (1, 2, 3, 4, 5, 6, 8) for cr in (1, 2, 4)
-            for da in (0, 1) if not (npl == 8 and cr == 4) and not (npl == 1 and da)] + ["-3,0,0,0"]
+# logit look-ahead kernel, explicit geometries -3,CR,RED,NPL (CR responses per workgroup, six waves
+# of 64 NPL rows; RED = 1: the vector waves finish the reduction of the partial sums, 2: the chain
+# wave does): ragged rows and responses, sweeps shorter and longer than the prefetch rings
+LA_GEOMS = [f"-3,{cr},{red},{npl}" for npl in (1, 2, 3, 4, 5, 6, 8) for cr in (1, 2, 4)
+            for red in (1, 2) if not (npl == 8 and cr == 4)] + ["-3,0,0,0"]
 
 
 @pytest.mark.parametrize("geom", LA_GEOMS)
 def test_logit_lookahead_geometries(oracle, hip, geom, monkeypatch):
-    _, cr, da, npl = map(int, geom.split(","))
-    n = 64 * (6 * npl - 4 * da) - 5 if npl else 300
+    _, cr, _, npl = map(int, geom.split(","))
+    n = 6 * 64 * npl - 5 if npl else 300
     p, d = 29, 2 * max(cr, 1) + 1
     inp = inputs_for("logit", n, p, d, seed=5)
     ref = call_variant(oracle, "logit", inp)
@@ -73,12 +73,12 @@ def test_logit_lookahead_geometries(oracle, hip, geom, monkeypatch):
     assert_parity(got, ref, what=f"logit look-ahead geom {geom}")
 
 
-@pytest.mark.parametrize("geom", ["-3,2,2,6", "-3,2,1,1", "-3,3,0,2", "-3,4,0,8", "-3,1,0,1", "-3,1,1,2",
+@pytest.mark.parametrize("geom", ["-3,2,3,6", "-3,2,-1,2", "-3,3,0,2", "-3,4,0,8", "-3,1,0,1", "-3,1,2,1",
                                   "-3,1,0,7"])
 def test_logit_lookahead_bad_geometry_is_refused(hip, geom, monkeypatch):
-    """A look-ahead geometry that does not exist (deal other than 0 / 1, uneven deal of one row per
-    lane, 3 responses per workgroup, 4 with NPL = 8, no NPL = 7) or does not cover n (6 * 64 rows
-    and 4 * 64 + 2 * 128 rows for n = 600) is an error before any launch: the caller's matrices are untouched."""
+    """A look-ahead geometry that does not exist (reduction mode other than 0 / 1 / 2, 3 responses
+    per workgroup, 4 with NPL = 8, no NPL = 7) or does not cover n (6 * 64 rows for n = 600) is an
+    error before any launch: the caller's matrices are untouched."""
     from locus_amd._lib import LocusHipError
     inp = inputs_for("logit", 600, 17, 5, seed=2)
     before = {k: np.array(inp[k], copy=True) for k in ("gam_vb", "beta_vb", "mat_x_m1", "mu_beta_vb")}
