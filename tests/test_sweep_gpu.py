@@ -73,6 +73,31 @@ def test_logit_lookahead_geometries(oracle, hip, geom, monkeypatch):
     assert_parity(got, ref, what=f"logit look-ahead geom {geom}")
 
 
+def _la_random_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(count):
+        n = int(rng.integers(20, 3073))
+        cr = int(rng.choice([1, 2, 4]))
+        if 64 * 6 * 6 < n:
+            cr = min(cr, 2)                      # CR = 4 is built up to NPL = 6
+        cases.append((n, int(rng.integers(1, 120)), int(rng.integers(1, 4 * cr + 2)), cr,
+                      int(rng.integers(1, 3))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _la_random_cases(24, seed=2024), ids=lambda c: "n%d_p%d_d%d_cr%d_red%d" % c)
+def test_logit_lookahead_random_shapes(oracle, hip, case, monkeypatch):
+    """Seeded random shapes up to the kernel's limit of 3072 rows, NPL chosen by the library, both
+    ways of finishing the reduction, sweeps of 1 .. 119 steps (shorter and longer than every ring)."""
+    n, p, d, cr, red = case
+    inp = inputs_for("logit", n, p, d, seed=n + 7 * p)
+    ref = call_variant(oracle, "logit", inp)
+    monkeypatch.setenv("LOCUS_HIP_SWEEP_CFG", f"-3,{cr},{red},0")
+    got = call_variant(hip, "logit", inp)
+    assert_parity(got, ref, what=f"logit look-ahead {case}")
+
+
 @pytest.mark.parametrize("geom", ["-3,2,3,6", "-3,2,-1,2", "-3,3,0,2", "-3,4,0,8", "-3,1,0,1", "-3,1,2,1",
                                   "-3,1,0,7"])
 def test_logit_lookahead_bad_geometry_is_refused(hip, geom, monkeypatch):
