@@ -230,11 +230,16 @@ class BinEngine:
     def iterate(self, shuffled_ind, alpha_order=None, before_readback=None):
         """One pass of the loop body (logistic_core.R:40-225 / probit_core.R:42-210).
         `before_readback()` runs on the host once every kernel of the iteration is queued and
-        before the host blocks on the read-back (the caller draws the next sweep order there)."""
+        before the host blocks on the read-back (the caller draws the next sweep order there and
+        may return it: see _pack_ahead)."""
         t, dv, host = self.torch, self.dv, self.host
         n, p, d, q = self.n, self.p, self.d_loc, self.q
         prm = host.begin_iteration()
-        ind = shuffled_ind if t.is_tensor(shuffled_ind) else self._up(shuffled_ind)
+        pre, self._pre_ind = getattr(self, "_pre_ind", None), None
+        if pre is not None and pre[0] is shuffled_ind:
+            ind = pre[1]           # uploaded, and its operands packed, while the last sweep ran
+        else:
+            ind = shuffled_ind if t.is_tensor(shuffled_ind) else self._up(shuffled_ind)
         lo, l1 = self._up(prm["lo"]), self._up(prm["l1"])
         order = range(q) if alpha_order is None else alpha_order
         if self.link == "logit":
@@ -291,7 +296,7 @@ class BinEngine:
         tot = host.exchange_t(rows[0], t.cat([sums[2].reshape(1), rs_m2a, loc.reshape(1), sum_log_s2a]))
         h_dev = t.cat([tot, host.rs_gam_t.sum().reshape(1), host.cov_t().reshape(1), ey.reshape(1)])
         if before_readback is not None:
-            before_readback()
+            self._pack_ahead(before_readback())
         h = h_dev.cpu().numpy()
         self.sweeper.status()
         host.sum_m2, host.rs_m2_alpha = float(h[0]), h[1:1 + q].copy()
@@ -304,6 +309,15 @@ class BinEngine:
             fn = lambda lz: E.e_alpha_probit_(host.rs_m2_alpha, self.s2a_vec, q, host.d, lz,  # noqa: E731
                                               host.zeta2_inv_vb)
         return host.finish_elbo(loc_sum, fn, cov=cov)
+
+    def _pack_ahead(self, next_ind):
+        """Probit (the matrix-core identity sweep): the next sweep's X-dependent operands are
+        packed on a side stream beside the running iteration (locus_core.IdentityEngine._pack_ahead)."""
+        if next_ind is None or self.link != "probit" or not hasattr(self.sweeper, "prepack"):
+            return
+        dev_ind = self.sweeper.prepack(next_ind)
+        if dev_ind is not None:
+            self._pre_ind = (next_ind, dev_ind)
 
     def held_out_elbo(self, lb_fit, Y_test_loc, X_test, Z_test):
         """elbo_probit_ on held-out rows (R/cross_validate.R:345-361).  Of its six terms only
@@ -393,6 +407,7 @@ def _run(link, Y, X, Z, list_hyper, gam_vb, alpha_vb, mu_beta_vb, sig2_alpha_vb,
         def draw_next(it=it):                 # while the GPU runs this iteration (0.2 ms at p = 20 000)
             if it < maxit:
                 nxt[it + 1] = draw(it + 1)
+                return nxt[it + 1][0]
         lb_new = eng.iterate(ind, a_order, before_readback=draw_next)
         if trace is not None:
             trace.append((it, lb_new))

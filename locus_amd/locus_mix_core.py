@@ -186,12 +186,17 @@ class MixEngine(IdentityEngine):
         self.host.set_initial(stats, rs_gam)
 
     def iterate(self, shuffled_ind, alpha_order=None, before_readback=None):
-        """`before_readback()`: host work of the caller (the next sweep order) once the kernels of
-        this iteration are queued, before the host blocks on the read-back."""
+        """`before_readback()`: host work of the caller once the kernels of this iteration are
+        queued, before the host blocks on the read-back; if it returns the next sweep order, that
+        sweep's X-dependent operands are packed on a side stream now (IdentityEngine._pack_ahead)."""
         dv, t = self.dv, self.torch
         n, d = self.n, self.d_loc
         prm = self.host.begin_iteration()
-        ind = shuffled_ind if t.is_tensor(shuffled_ind) else self._up(shuffled_ind)
+        pre, self._pre_ind = getattr(self, "_pre_ind", None), None
+        if pre is not None and pre[0] is shuffled_ind:
+            ind = pre[1]           # uploaded, and its operands packed, while the last sweep ran
+        else:
+            ind = shuffled_ind if t.is_tensor(shuffled_ind) else self._up(shuffled_ind)
         # the iteration's constants in one upload (seven small copies before)
         coef, lo, l1, scale, hinv, cst, s2k = self._up_many(
             prm["alpha_coef"], prm["lo"], prm["l1"], prm["scale"], prm["hinv"], prm["cst"], prm["s2k"])
@@ -204,7 +209,7 @@ class MixEngine(IdentityEngine):
         ey_bin = self._update_W(True)
         h_dev = t.cat([self.stats.reshape(-1), ent.sum().reshape(1), self.alpha.reshape(-1)])
         if before_readback is not None:
-            before_readback()
+            self._pack_ahead(before_readback())   # the next sweep order, if the caller returns it
         h = h_dev.cpu().numpy()
         self.sweeper.status()
         return self.host.end_iteration(h[: 4 * d].reshape(4, d), rs_gam, float(h[4 * d]),
@@ -309,6 +314,7 @@ def locus_mix_core_(Y, X, Z, ind_bin, list_hyper, gam_vb, alpha_vb, mu_beta_vb, 
         def draw_next(it=it):                 # while the GPU runs this iteration
             if it < maxit:
                 nxt[it + 1] = draw(it + 1)
+                return nxt[it + 1][0]         # packed ahead by the engine, beside the running sweep
         lb_new = eng.iterate(ind, alpha_order=a_order, before_readback=draw_next)
         if trace is not None:
             trace.append((it, lb_new))
